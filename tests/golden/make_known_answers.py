@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/reference_known_answers.json.
+
+Every case is a known-answer the REFERENCE's own test-suite asserts for the
+ingest -> finalize path, restated as data (inputs + expected outputs); the
+`source` field cites the reference test (file:line).  Cases tagged
+"survey-verified" are the quirk probes SURVEY.md section 8a records as "[verified by
+running the reference]" (expected arrays as observed there).  Nothing here is
+computed by this repository's code: expected values are literals from those sources.
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAN = "nan"   # JSON has no NaN literal; tests map the string back
+
+
+def grid(bounds, cell=(1.0, -1.0), tile=(4096, 4096), dims=None):
+    return {"bounds": list(bounds), "cell": list(cell), "tile": list(tile),
+            "dims": list(dims) if dims else None}
+
+
+def cell_centres_10x10():
+    xs, ys = [], []
+    for i in range(10):
+        for j in range(10):
+            xs.append(0.5 + j)
+            ys.append(9.5 - i)
+    return xs, ys
+
+
+G10 = grid((0.0, 0.0, 10.0, 10.0), tile=(5, 5), dims=(10, 10))   # test_pipeline.cpp:22-30
+
+pipeline = []
+
+xs, ys = cell_centres_10x10()
+pipeline.append({
+    "name": "SingleCloud_Sum", "source": "tests/cpp/test_pipeline.cpp:66-120",
+    "grid": G10, "reductions": [{"type": "Sum"}],
+    "clouds": [{"x": xs, "y": ys, "value": [1.0] * 100}],
+    "expected": [[1.0] * 100], "compare": "float_eq"})
+
+x2, y2, v2 = [], [], []
+for i in range(10):
+    for j in range(10):
+        x2 += [0.3 + j, 0.7 + j]
+        y2 += [9.7 - i, 9.3 - i]
+        v2 += [10.0, 20.0]
+pipeline.append({
+    "name": "SingleCloud_Average", "source": "tests/cpp/test_pipeline.cpp:122-171",
+    "grid": G10, "reductions": [{"type": "Average"}],
+    "clouds": [{"x": x2, "y": y2, "value": v2}],
+    "expected": [[15.0] * 100], "compare": "float_eq"})
+
+pipeline.append({
+    "name": "MultipleReductions", "source": "tests/cpp/test_pipeline.cpp:173-233",
+    "grid": G10, "reductions": [{"type": "Sum"}, {"type": "Max"}, {"type": "Count"}],
+    "clouds": [{"x": xs, "y": ys, "value": [float(i) for i in range(100)]}],
+    "expected": [[float(i) for i in range(100)], [float(i) for i in range(100)], [1.0] * 100],
+    "compare": "float_eq"})
+
+xa = [0.5 + (i % 10) for i in range(50)]
+ya = [9.5 - (i // 10) for i in range(50)]
+pipeline.append({
+    "name": "MultipleClouds", "source": "tests/cpp/test_pipeline.cpp:235-303",
+    "grid": G10, "reductions": [{"type": "Sum"}],
+    "clouds": [{"x": xa, "y": ya, "value": [10.0] * 50}, {"x": xa, "y": ya, "value": [20.0] * 50}],
+    "expected": [[30.0] * 50 + [NAN] * 50], "compare": "float_eq",
+    "note": "rows 5-9 lie in untouched tiles -> NaN (quirk Q3)"})
+
+# --- SURVEY section 8a quirk probes, [verified by running the reference] -----------------
+G4 = grid((0.0, 0.0, 4.0, 4.0), tile=(2, 2), dims=(4, 4))
+pipeline.append({
+    "name": "Q2_sum_zero_vs_nan_in_touched_tile", "source": "survey-verified SURVEY.md:351 (Q2)/(Q3)",
+    "grid": G4, "reductions": [{"type": "Sum"}, {"type": "Count"}, {"type": "Average"},
+                               {"type": "Max"}, {"type": "Min"}],
+    "clouds": [{"x": [0.5], "y": [3.5], "value": [7.0]}],
+    # tile (0,0) = rows 0-1, cols 0-1 touched; rest untouched -> NaN for every op
+    "expected": [
+        [7.0, 0.0, NAN, NAN, 0.0, 0.0, NAN, NAN] + [NAN] * 8,
+        [1.0, NAN, NAN, NAN, NAN, NAN, NAN, NAN] + [NAN] * 8,
+        [7.0, NAN, NAN, NAN, NAN, NAN, NAN, NAN] + [NAN] * 8,
+        [7.0, NAN, NAN, NAN, NAN, NAN, NAN, NAN] + [NAN] * 8,
+        [7.0, NAN, NAN, NAN, NAN, NAN, NAN, NAN] + [NAN] * 8],
+    "compare": "float_eq"})
+
+pipeline.append({
+    "name": "Q8_weighted_average_point_is_average", "source": "survey-verified SURVEY.md:367 (Q8)",
+    "grid": grid((0.0, 0.0, 4.0, 4.0), dims=(4, 4)), "reductions": [{"type": "WeightedAverage"}],
+    "clouds": [{"x": [0.5, 0.5], "y": [3.5, 3.5], "value": [1.0, 3.0]}],
+    "expected": [[2.0] + [NAN] * 15], "compare": "float_eq"})
+
+world_to_cell = [
+    # test_grid_config.cpp:81-110 on make_test_grid_config(0,0,100,100,1) (tile 256)
+    {"source": "tests/cpp/test_grid_config.cpp:81-90", "grid": grid((0, 0, 100, 100), tile=(256, 256)),
+     "wx": 50.0, "wy": 50.0, "valid": True, "col": 50, "row": 50},
+    {"source": "tests/cpp/test_grid_config.cpp:92-101", "grid": grid((0, 0, 100, 100), tile=(256, 256)),
+     "wx": 0.0, "wy": 100.0, "valid": True, "col": 0, "row": 0},
+    {"source": "tests/cpp/test_grid_config.cpp:103-110", "grid": grid((0, 0, 100, 100), tile=(256, 256)),
+     "wx": -10.0, "wy": 50.0, "valid": False},
+    # quirk Q1, SURVEY.md:348-350: inclusive bounds + clamp on a 4x4 grid
+    {"source": "survey-verified SURVEY.md:349 (Q1)", "grid": grid((0, 0, 4, 4), dims=(4, 4)),
+     "wx": 0.0, "wy": 0.0, "valid": True, "col": 0, "row": 3},
+    {"source": "survey-verified SURVEY.md:349 (Q1)", "grid": grid((0, 0, 4, 4), dims=(4, 4)),
+     "wx": 4.0, "wy": 4.0, "valid": True, "col": 3, "row": 0},
+    {"source": "survey-verified SURVEY.md:349 (Q1)", "grid": grid((0, 0, 4, 4), dims=(4, 4)),
+     "wx": 4.0, "wy": 0.0, "valid": True, "col": 3, "row": 3},
+    {"source": "survey-verified SURVEY.md:349 (Q1)", "grid": grid((0, 0, 4, 4), dims=(4, 4)),
+     "wx": 2.0, "wy": 4.0, "valid": True, "col": 2, "row": 0},
+    # test_tile_router.cpp:86-120 on the 10x10 grid
+    {"source": "tests/cpp/test_tile_router.cpp:94", "grid": G10, "wx": -1.0, "wy": 5.0, "valid": False},
+    {"source": "tests/cpp/test_tile_router.cpp:95", "grid": G10, "wx": 5.0, "wy": -1.0, "valid": False},
+    {"source": "tests/cpp/test_tile_router.cpp:96", "grid": G10, "wx": 15.0, "wy": 5.0, "valid": False},
+    {"source": "tests/cpp/test_tile_router.cpp:97", "grid": G10, "wx": 5.0, "wy": 15.0, "valid": False},
+    {"source": "tests/cpp/test_tile_router.cpp:98", "grid": G10, "wx": 5.0, "wy": 5.0, "valid": True,
+     "col": 5, "row": 5},
+]
+
+compute_dimensions = [
+    {"source": "tests/cpp/test_grid_config.cpp:12-29", "grid": grid((0, 0, 100, 100), tile=(32, 32)),
+     "width": 100, "height": 100, "tiles_x": 4, "tiles_y": 4},
+    {"source": "tests/cpp/test_grid_config.cpp:31-44", "grid": grid((0, 0, 100.5, 100.5)),
+     "width": 101, "height": 101, "tiles_x": 1, "tiles_y": 1},
+    {"source": "tests/cpp/test_grid_config.cpp:46-63",
+     "grid": grid((0, 0, 1000, 1000), cell=(10.0, -10.0), tile=(50, 50)),
+     "width": 100, "height": 100, "tiles_x": 2, "tiles_y": 2},
+]
+
+tile_cell_range = [
+    {"source": "tests/cpp/test_grid_config.cpp:171-185", "grid": grid((0, 0, 1000, 1000), tile=(256, 256)),
+     "tile_row": 1, "tile_col": 1, "expect": [256, 256, 256, 256]},
+    {"source": "tests/cpp/test_grid_config.cpp:187-210", "grid": grid((0, 0, 300, 300), tile=(256, 256)),
+     "tile_row": 1, "tile_col": 1, "expect": [256, 256, 44, 44]},
+]
+
+# Router assignment: test_tile_router.cpp:48-84 -- cell i of the 10x10 grid for point i,
+# tile (row/5)*2 + col/5; :202-263 -- local index 0 for one point per 2x2 tile of a 4x4 grid.
+router = [
+    {"source": "tests/cpp/test_tile_router.cpp:48-84", "grid": G10, "x": xs, "y": ys,
+     "cell": list(range(100)),
+     "tile": [((i // 10) // 5) * 2 + (i % 10) // 5 for i in range(100)]},
+    {"source": "tests/cpp/test_tile_router.cpp:202-263", "grid": G4,
+     "x": [0.5, 2.5, 0.5, 2.5], "y": [3.5, 3.5, 1.5, 1.5],
+     "cell": [0, 2, 8, 10], "tile": [0, 1, 2, 3], "local": [0, 0, 0, 0]},
+]
+
+# Tile-state known answers (band-sequential state).
+state_ops = [
+    {"source": "tests/cpp/test_reduction_ops.cpp:212-248", "type": "Sum", "tile_cells": 9,
+     "cells": [0, 0, 1, 2, 2, 2, 4], "values": [10, 20, 30, 5, 5, 5, 100],
+     "state": [30.0, 30.0, 15.0, 0.0, 100.0, 0.0, 0.0, 0.0, 0.0]},
+    {"source": "tests/cpp/test_reduction_ops.cpp:250-283", "type": "Average", "tile_cells": 5,
+     "cells": [0, 0, 0, 1, 1], "values": [10, 20, 30, 50, 50],
+     "final": [20.0, 50.0, NAN, NAN, NAN]},
+    {"source": "tests/cpp/test_accumulator.cpp:137-179", "type": "Average", "tile_cells": 10,
+     "cells": [0, 1, 0], "values": [10.0, 30.0, 20.0],
+     "state": [30.0, 30.0] + [0.0] * 8 + [2.0, 1.0] + [0.0] * 8,
+     "final": [15.0, 30.0] + [NAN] * 8},
+    {"source": "tests/cpp/test_accumulator.cpp:181-221", "type": "Sum", "tile_cells": 5,
+     "batches": [{"cells": [0, 1, 2], "values": [10.0, 20.0, 30.0]},
+                 {"cells": [0, 1, 2], "values": [5.0, 10.0, 15.0]}],
+     "state": [15.0, 30.0, 45.0, 0.0, 0.0]},
+    # op identities / NaN-on-empty: test_reduction_ops.cpp:51-55, 74-78, 97-101, 133-137
+    {"source": "tests/cpp/test_reduction_ops.cpp:51-55,74-78,97-101,133-137", "type": "Max",
+     "tile_cells": 2, "cells": [0, 0, 0], "values": [10.0, 5.0, 15.0], "final": [15.0, NAN]},
+    {"source": "tests/cpp/test_reduction_ops.cpp:57-72", "type": "Min",
+     "tile_cells": 2, "cells": [0, 0, 0], "values": [10.0, 15.0, 5.0], "final": [5.0, NAN]},
+    {"source": "tests/cpp/test_reduction_ops.cpp:80-101", "type": "Count",
+     "tile_cells": 2, "cells": [1, 1, 1], "values": [1.0, 2.0, 3.0], "final": [NAN, 3.0]},
+]
+
+# Glyph quirk probes (8x8 grid), SURVEY.md:354-366, [verified by running the reference].
+glyph = [
+    {"name": "Q5_gaussian_corner_sampling", "source": "survey-verified SURVEY.md:357-360 (Q5)",
+     "grid": grid((0, 0, 8, 8), dims=(8, 8)),
+     "spec": {"glyph": "Gaussian", "type": "Sum", "sigma": 1.0, "max_radius": 4.0},
+     "x": [3.5], "y": [4.5], "value": [1.0],
+     # point at the centre of cell (col 3, row 3): weight exp(-0.25)=0.7788 in (3,3),(4,3),(3,4),(4,4);
+     # one step towards -x/-y: 0.2865, two: 0.1054 (diag 0.0388)
+     "probes": [[3, 3, 0.7788008], [3, 4, 0.7788008], [4, 3, 0.7788008], [4, 4, 0.7788008],
+                [3, 2, 0.2865048], [2, 3, 0.2865048], [2, 2, 0.1053992], [3, 1, 0.0387742]],
+     "rtol": 1e-5},
+    {"name": "Q4_gaussian_tile_clip", "source": "survey-verified SURVEY.md:354-356 (Q4)",
+     "grid": grid((0, 0, 8, 8), tile=(4, 4), dims=(8, 8)),
+     "spec": {"glyph": "Gaussian", "type": "WeightedAverage", "sigma": 1.0, "max_radius": 4.0},
+     "x": [3.5], "y": [4.5], "value": [1.0],
+     "nan_cols_from": 4, "nan_rows_from": 4},
+    {"name": "Q7_line_rounding", "source": "survey-verified SURVEY.md:363-366 (Q7)",
+     "grid": grid((0, 0, 8, 8), dims=(8, 8)),
+     "spec": {"glyph": "Line", "type": "Count", "direction": 0.0, "half_length": 2.0, "max_radius": 32.0},
+     "x": [4.5], "y": [4.5], "value": [1.0],
+     # y=4.5 is row 3 (fcy=3.5); round(3.5)=4 -> drawn in row 4; x: round(2.5)=3 .. round(6.5)=7
+     "cells_set": [[4, 3], [4, 4], [4, 5], [4, 6], [4, 7]]},
+]
+
+out = {"pipeline": pipeline, "world_to_cell": world_to_cell,
+       "compute_dimensions": compute_dimensions, "tile_cell_range": tile_cell_range,
+       "router": router, "state_ops": state_ops, "glyph": glyph}
+
+with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("wrote reference_known_answers.json:", {k: len(v) for k, v in out.items()})
