@@ -1,0 +1,188 @@
+/*
+ * pcr_hip.h -- C-ABI of libpcr_hip.so: the MI355X (gfx950) engine behind
+ * pcr::Pipeline::ingest / finalize.
+ *
+ * Plain C: opaque handles, raw host/device pointers and sizes; no C++ or torch types.
+ * Every function returns a pcr_hip_status (same numbering as the reference's
+ * pcr::StatusCode, include/pcr/core/types.h:118-126; HIP failures map to
+ * PCR_HIP_CUDA_ERROR to keep the reference's code name); the message of the last
+ * failure on the calling thread is pcr_hip_last_error().
+ *
+ * The reference has no C ABI of its own.  Each entry point replaces one of its C++
+ * seams, cited as "replaces:" (file:line into BigHippo123/pointcloud-raster).
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Layout conventions
+ *   - points: SoA, x/y float64, channels float32 (include/pcr/core/point_cloud.h:29-103)
+ *   - state:  band-sequential float32 planes in GRID layout, plane f at
+ *             base + f*plane_stride, cell (row, col) at (row - state_row0)*width + col
+ *             (the reference keeps per-tile planes, include/pcr/ops/reduction_op.h:45;
+ *             tiles here are only a semantic: clip rectangle + "touched" flag)
+ *   - all pointers named d_* are device pointers, h_* host pointers.
+ */
+#ifndef PCR_HIP_H
+#define PCR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCR_HIP_ABI_VERSION 1
+
+typedef enum pcr_hip_status {
+    PCR_HIP_OK = 0,
+    PCR_HIP_INVALID_ARGUMENT = 1,
+    PCR_HIP_OUT_OF_MEMORY = 2,
+    PCR_HIP_CUDA_ERROR = 3,        /* a HIP runtime failure (name kept from the reference) */
+    PCR_HIP_IO_ERROR = 4,
+    PCR_HIP_CRS_ERROR = 5,
+    PCR_HIP_NOT_IMPLEMENTED = 6
+} pcr_hip_status;
+
+/* pcr::ReductionType numbering (types.h:33-45); only these six are registered
+ * (src/ops/reduction_registry.cpp:173-184). */
+enum {
+    PCR_HIP_SUM = 0, PCR_HIP_MAX = 1, PCR_HIP_MIN = 2,
+    PCR_HIP_AVERAGE = 3, PCR_HIP_WEIGHTED_AVERAGE = 4, PCR_HIP_COUNT = 5
+};
+
+/* pcr::GlyphType numbering (include/pcr/engine/glyph.h:11-15). */
+enum { PCR_HIP_GLYPH_POINT = 0, PCR_HIP_GLYPH_LINE = 1, PCR_HIP_GLYPH_GAUSSIAN = 2 };
+
+/* Accumulation planes a scatter can feed in one pass over the points. */
+enum {
+    PCR_HIP_PLANE_SUM = 1u,   /* += value * w        (Sum; numerator of Average/WeightedAverage) */
+    PCR_HIP_PLANE_WGT = 2u,   /* += w  (w = 1 for the Point glyph: Count; denominator)           */
+    PCR_HIP_PLANE_MAX = 4u,   /* fmaxf, identity -FLT_MAX (Point glyph only)                      */
+    PCR_HIP_PLANE_MIN = 8u    /* fminf, identity +FLT_MAX (Point glyph only)                      */
+};
+
+typedef void* pcr_hip_stream;      /* hipStream_t; NULL = the null stream */
+
+/* The fields of pcr::GridConfig the hot path reads (include/pcr/core/grid_config.h:17-38)
+ * plus the row window a device holds when the grid is row-block sharded over GPUs. */
+typedef struct pcr_hip_grid {
+    double min_x, min_y, max_x, max_y;   /* bounds; origin is (min_x, max_y) */
+    double cell_size_x, cell_size_y;     /* cell_size_y < 0 on north-up grids */
+    int32_t width, height;               /* whole grid, cells */
+    int32_t tile_width, tile_height;     /* reference tiling (clip + touched semantics) */
+    int32_t own_row0, own_row1;          /* this device ingests points whose centre row is in [own_row0, own_row1) */
+    int32_t state_row0, state_rows;      /* rows held in the state planes: [state_row0, state_row0 + state_rows) */
+} pcr_hip_grid;
+
+/* Device planes of one accumulation group.  A NULL plane is not accumulated. */
+typedef struct pcr_hip_planes {
+    float* d_sum;
+    float* d_wgt;
+    float* d_max;
+    float* d_min;
+} pcr_hip_planes;
+
+/* pcr::GlyphSpec numeric fields (glyph.h:20-42) + per-point channel arrays (device, may be NULL). */
+typedef struct pcr_hip_glyph {
+    int32_t type;
+    float default_direction, default_half_length;
+    float default_sigma_x, default_sigma_y, default_rotation;
+    float max_radius_cells;
+    const float* d_direction;
+    const float* d_half_length;
+    const float* d_sigma_x;
+    const float* d_sigma_y;
+    const float* d_rotation;
+} pcr_hip_glyph;
+
+/* Counters of the last scatter on an engine (diagnostics; exact). */
+typedef struct pcr_hip_scatter_stats {
+    uint64_t points_in;        /* points offered */
+    uint64_t points_valid;     /* inside bounds and inside [own_row0, own_row1) */
+    int32_t path;              /* 0 = direct global atomics, 1 = binned LDS tiles */
+    int32_t lds_tile_w, lds_tile_h, lds_apron, num_bins;
+} pcr_hip_scatter_stats;
+
+const char* pcr_hip_last_error(void);
+int pcr_hip_abi_version(void);
+
+/* ---- devices.  replaces: cuda_device_available/count/name/get_memory_info,
+ *      include/pcr/core/types.h:156-219, and cudaSetDevice in src/engine/pipeline.cpp:133-160 */
+int pcr_hip_device_count(int* count);
+int pcr_hip_set_device(int device_id);
+int pcr_hip_get_device(int* device_id);
+int pcr_hip_device_name(int device_id, char* buf, size_t buf_len);
+int pcr_hip_mem_info(size_t* free_bytes, size_t* total_bytes);
+int pcr_hip_device_synchronize(void);
+
+/* ---- streams / events.  replaces: the single cudaStream of src/engine/pipeline.cpp:198-213 */
+int pcr_hip_stream_create(pcr_hip_stream* out);
+int pcr_hip_stream_destroy(pcr_hip_stream s);
+int pcr_hip_stream_synchronize(pcr_hip_stream s);
+int pcr_hip_event_create(void** out);
+int pcr_hip_event_destroy(void* ev);
+int pcr_hip_event_record(void* ev, pcr_hip_stream s);
+int pcr_hip_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronizes on ev_stop */
+
+/* ---- memory.  replaces: cudaMalloc/cudaMallocHost/cudaMemcpy* in src/core/point_cloud.cpp:55-73,
+ *      382-512 (PointCloud::to / to_device_async) and src/core/grid.cpp device paths */
+int pcr_hip_malloc(void** d_ptr, size_t bytes);
+int pcr_hip_free(void* d_ptr);
+int pcr_hip_host_alloc(void** h_ptr, size_t bytes);          /* pinned */
+int pcr_hip_host_free(void* h_ptr);
+int pcr_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, pcr_hip_stream s);  /* async when h_src is pinned */
+int pcr_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, pcr_hip_stream s);
+int pcr_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, pcr_hip_stream s);
+int pcr_hip_memset(void* d_ptr, int byte_value, size_t bytes, pcr_hip_stream s);
+
+/* ---- arena.  replaces: pcr::MemoryPool (include/pcr/engine/memory_pool.h:18-50,
+ *      src/engine/memory_pool.cu:24-59): bump allocator over one device allocation, 256-B aligned */
+typedef struct pcr_hip_arena pcr_hip_arena;
+int pcr_hip_arena_create(pcr_hip_arena** out, size_t bytes);
+int pcr_hip_arena_destroy(pcr_hip_arena* a);
+int pcr_hip_arena_alloc(pcr_hip_arena* a, size_t bytes, void** d_ptr);
+int pcr_hip_arena_reset(pcr_hip_arena* a);
+int pcr_hip_arena_stats(const pcr_hip_arena* a, size_t* capacity, size_t* used, size_t* high_water);
+
+/* ---- state planes.  replaces: init_tile_state / merge_tile_state / finalize_tile,
+ *      include/pcr/engine/grid_merge.h:22-41 (src/engine/grid_merge.cu:116-183), and the CPU
+ *      finalize loop of src/engine/pipeline.cpp:1204-1286 (NaN fill, untouched tiles skipped) */
+int pcr_hip_state_floats(int rtype, int* k);                                   /* reduction_registry.cpp:197-208 */
+int pcr_hip_plane_fill(float* d_plane, float value, int64_t cells, pcr_hip_stream s);
+int pcr_hip_state_init(int rtype, float* d_state, int64_t cells, pcr_hip_stream s);         /* K planes, stride = cells */
+int pcr_hip_state_merge(int rtype, float* d_dst, const float* d_src, int64_t cells, pcr_hip_stream s);
+/* merge one plane with the op of its PCR_HIP_PLANE_* kind (add / fmaxf / fminf): halo rows, multi-ingest merges */
+int pcr_hip_plane_merge(uint32_t plane_kind, float* d_dst, const float* d_src, int64_t cells, pcr_hip_stream s);
+/* out[row, col] for rows [own_row0, own_row1): finalize(rtype) of the planes where the cell's
+ * reference tile is touched, NaN elsewhere.  d_out holds (own_row1-own_row0)*width floats.
+ * d_tile_touched: tiles_x*tiles_y words (NULL = all touched). */
+int pcr_hip_finalize(int rtype, const pcr_hip_grid* g, const pcr_hip_planes* planes,
+                     const uint32_t* d_tile_touched, float* d_out, pcr_hip_stream s);
+
+/* ---- scatter engine.  replaces: TileRouter::assign + sort + extract_batches
+ *      (include/pcr/engine/tile_router_kernels.h:15-52, src/engine/tile_router.cpp:51-366),
+ *      Accumulator::accumulate (include/pcr/engine/accumulator_kernels.h:13-23,
+ *      src/engine/accumulator.cpp:33-59) and accumulate_glyph
+ *      (include/pcr/engine/glyph_kernels.h:31-42), fused: no sort, no materialised indices. */
+typedef struct pcr_hip_engine pcr_hip_engine;
+/* scratch_bytes = 0: the engine grows its scratch arena on demand. */
+int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s);
+int pcr_hip_engine_destroy(pcr_hip_engine* e);
+/* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot be binned) */
+int pcr_hip_engine_set_path(pcr_hip_engine* e, int path);
+int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
+/* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */
+int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, int32_t* tiles_x, int32_t* tiles_y);
+
+/* Point glyph: every valid point folds `value` into the planes named by plane_mask at its cell.
+ * d_value may be NULL only when plane_mask == PCR_HIP_PLANE_WGT. */
+int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_planes* planes,
+                          const double* d_x, const double* d_y, const float* d_value, uint64_t n);
+/* Line / Gaussian glyph: planes SUM (+= v*w) and/or WGT (+= w) only. */
+int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_t plane_mask,
+                          const pcr_hip_planes* planes,
+                          const double* d_x, const double* d_y, const float* d_value, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

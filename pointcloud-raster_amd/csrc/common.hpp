@@ -1,0 +1,127 @@
+// common.hpp -- shared host/device definitions of libpcr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "pcr_hip.h"
+
+namespace pcrhip {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define PCR_HIP_TRY(expr)                                                              \
+    do {                                                                               \
+        hipError_t pcr_e_ = (expr);                                                    \
+        if (pcr_e_ != hipSuccess)                                                      \
+            return ::pcrhip::fail(                                                     \
+                pcr_e_ == hipErrorOutOfMemory ? PCR_HIP_OUT_OF_MEMORY : PCR_HIP_CUDA_ERROR, \
+                std::string("HIP error: ") + hipGetErrorString(pcr_e_) + " (" #expr ")"); \
+    } while (0)
+
+#define PCR_REQUIRE(cond, msg)                                                         \
+    do {                                                                               \
+        if (!(cond)) return ::pcrhip::fail(PCR_HIP_INVALID_ARGUMENT, msg);             \
+    } while (0)
+
+// ---- device-side grid descriptor --------------------------------------------
+struct GridDev {
+    double min_x, min_y, max_x, max_y;
+    double csx, csy;
+    double inv_csx, inv_csy;          // 1.0 / cell size, as the glyph code uses (glyph_kernels.cu:97-98)
+    int W, H;
+    int tw, th, tiles_x, tiles_y;
+    int own_r0, own_r1;
+    int st_r0, st_rows;
+};
+
+struct PlanesDev {
+    float* sum;
+    float* wgt;
+    float* mx;
+    float* mn;
+};
+
+struct GlyphDev {
+    int type;
+    float def_direction, def_half_length, def_sigma_x, def_sigma_y, def_rotation, max_radius;
+    const float* direction;
+    const float* half_length;
+    const float* sigma_x;
+    const float* sigma_y;
+    const float* rotation;
+};
+
+inline GridDev make_grid_dev(const pcr_hip_grid& g) {
+    GridDev d;
+    d.min_x = g.min_x; d.min_y = g.min_y; d.max_x = g.max_x; d.max_y = g.max_y;
+    d.csx = g.cell_size_x; d.csy = g.cell_size_y;
+    d.inv_csx = 1.0 / g.cell_size_x; d.inv_csy = 1.0 / g.cell_size_y;
+    d.W = g.width; d.H = g.height;
+    d.tw = g.tile_width; d.th = g.tile_height;
+    d.tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
+    d.tiles_y = (g.height + g.tile_height - 1) / g.tile_height;
+    d.own_r0 = g.own_row0; d.own_r1 = g.own_row1;
+    d.st_r0 = g.state_row0; d.st_rows = g.state_rows;
+    return d;
+}
+
+int validate_grid(const pcr_hip_grid* g);
+
+#if defined(__HIPCC__)
+
+// ---- routing: GridConfig::world_to_cell (src/core/grid_config.cpp:24-43) ------
+// Inclusive bounds (BBox::contains, src/core/types.cpp:41-43), floor of a TRUE f64
+// division, clamp.  NaN coordinates fail the bounds test, as on the CPU.
+__device__ __forceinline__ bool world_to_cell(const GridDev& g, double wx, double wy, int& col, int& row) {
+    if (!(wx >= g.min_x && wx <= g.max_x && wy >= g.min_y && wy <= g.max_y)) return false;
+    int c = (int)floor((wx - g.min_x) / g.csx);
+    int r = (int)floor((wy - g.max_y) / g.csy);
+    c = max(0, min(c, g.W - 1));
+    r = max(0, min(r, g.H - 1));
+    col = c;
+    row = r;
+    return true;
+}
+
+// ---- float atomics ------------------------------------------------------------
+// Sum planes: hardware global_atomic_add_f32 / ds_add_f32 (no CAS loop; built with
+// -munsafe-fp-atomics).
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// fmaxf / fminf folds (MaxOp/MinOp::combine, include/pcr/ops/builtin_ops.h:27,40) as
+// integer atomics on the float's bits: for sign-clear values the signed-int order is the
+// float order; for sign-set values the unsigned order is the reverse float order.
+// NaN values are skipped (fmaxf(acc, NaN) == acc).  Works for global and LDS addresses.
+__device__ __forceinline__ void atomic_max_f32(float* p, float v) {
+    if (v != v) return;
+    unsigned b = __float_as_uint(v);
+    if (!(b & 0x80000000u)) atomicMax(reinterpret_cast<int*>(p), (int)b);
+    else atomicMin(reinterpret_cast<unsigned*>(p), b);
+}
+__device__ __forceinline__ void atomic_min_f32(float* p, float v) {
+    if (v != v) return;
+    unsigned b = __float_as_uint(v);
+    if (!(b & 0x80000000u)) atomicMin(reinterpret_cast<int*>(p), (int)b);
+    else atomicMax(reinterpret_cast<unsigned*>(p), b);
+}
+
+// Mark the reference tile of (row, col) as having state (pipeline.cpp:688-691, 1220).
+__device__ __forceinline__ void touch_tile(const GridDev& g, uint32_t* touched, int row, int col) {
+    int t = (row / g.th) * g.tiles_x + (col / g.tw);
+    // agent-scope relaxed load: served by L2, never by a stale L1 line, so the flag is
+    // written only until the first store lands.
+    if (__hip_atomic_load(touched + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __hip_atomic_store(touched + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace pcrhip

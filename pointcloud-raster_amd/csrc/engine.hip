@@ -1,0 +1,184 @@
+// engine.hip -- pcr_hip_engine_* and pcr_hip_scatter_*: argument checking, path choice
+// (direct global atomics vs binned LDS tiles), bookkeeping.  Kernels live in
+// scatter_direct.hip / scatter_binned.hip.
+#include "engine.hpp"
+
+#include <new>
+
+using namespace pcrhip;
+
+namespace pcrhip {
+
+int ensure_scratch(pcr_hip_engine* e, size_t bytes) {
+    if (bytes <= e->scratch_cap) return PCR_HIP_OK;
+    // grow-only; growth happens on the first ingest of a given size (outside steady state).
+    // Free after the stream drains: earlier kernels may still read the old block.
+    if (e->d_scratch) {
+        PCR_HIP_TRY(hipStreamSynchronize(e->stream));
+        PCR_HIP_TRY(hipFree(e->d_scratch));
+        e->d_scratch = nullptr;
+        e->scratch_cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_scratch), want));
+    e->scratch_cap = want;
+    return PCR_HIP_OK;
+}
+
+}  // namespace pcrhip
+
+namespace {
+
+int check_planes(uint32_t mask, const pcr_hip_planes* p, uint32_t allowed, PlanesDev& out) {
+    PCR_REQUIRE(p != nullptr, "scatter: null planes");
+    PCR_REQUIRE(mask != 0 && (mask & ~allowed) == 0, "scatter: plane mask not supported for this glyph");
+    PCR_REQUIRE(!(mask & PCR_HIP_PLANE_SUM) || p->d_sum, "scatter: SUM plane requested but d_sum is null");
+    PCR_REQUIRE(!(mask & PCR_HIP_PLANE_WGT) || p->d_wgt, "scatter: WGT plane requested but d_wgt is null");
+    PCR_REQUIRE(!(mask & PCR_HIP_PLANE_MAX) || p->d_max, "scatter: MAX plane requested but d_max is null");
+    PCR_REQUIRE(!(mask & PCR_HIP_PLANE_MIN) || p->d_min, "scatter: MIN plane requested but d_min is null");
+    out.sum = p->d_sum; out.wgt = p->d_wgt; out.mx = p->d_max; out.mn = p->d_min;
+    return PCR_HIP_OK;
+}
+
+int begin_scatter(pcr_hip_engine* e, uint64_t n) {
+    e->stats.points_in = n;
+    e->stats.points_valid = 0;
+    e->stats.lds_tile_w = e->stats.lds_tile_h = e->stats.lds_apron = e->stats.num_bins = 0;
+    PCR_HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
+    return PCR_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s) {
+    PCR_REQUIRE(out, "engine_create: null out pointer");
+    *out = nullptr;
+    int rc = validate_grid(g);
+    if (rc) return rc;
+    auto* e = new (std::nothrow) pcr_hip_engine();
+    if (!e) return fail(PCR_HIP_OUT_OF_MEMORY, "engine_create: host allocation failed");
+    e->grid = *g;
+    e->gd = make_grid_dev(*g);
+    e->stream = static_cast<hipStream_t>(s);
+    hipError_t err = hipGetDevice(&e->device);
+    hipDeviceProp_t prop;
+    if (err == hipSuccess) err = hipGetDeviceProperties(&prop, e->device);
+    if (err == hipSuccess) {
+        e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        e->ntiles = e->gd.tiles_x * e->gd.tiles_y;
+        err = hipMalloc(reinterpret_cast<void**>(&e->d_touched), (size_t)e->ntiles * sizeof(uint32_t));
+    }
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&e->d_counters), 8 * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMemsetAsync(e->d_touched, 0, (size_t)e->ntiles * sizeof(uint32_t), e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream);
+    if (err == hipSuccess && scratch_bytes) {
+        err = hipMalloc(reinterpret_cast<void**>(&e->d_scratch), scratch_bytes);
+        if (err == hipSuccess) e->scratch_cap = scratch_bytes;
+    }
+    if (err != hipSuccess) {
+        std::string msg = std::string("engine_create: ") + hipGetErrorString(err);
+        pcr_hip_engine_destroy(e);
+        return fail(err == hipErrorOutOfMemory ? PCR_HIP_OUT_OF_MEMORY : PCR_HIP_CUDA_ERROR, msg);
+    }
+    *out = e;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_destroy(pcr_hip_engine* e) {
+    if (!e) return PCR_HIP_OK;
+    (void)hipStreamSynchronize(e->stream);
+    if (e->d_touched) (void)hipFree(e->d_touched);
+    if (e->d_counters) (void)hipFree(e->d_counters);
+    if (e->d_scratch) (void)hipFree(e->d_scratch);
+    delete e;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_set_path(pcr_hip_engine* e, int path) {
+    PCR_REQUIRE(e, "engine_set_path: null engine");
+    PCR_REQUIRE(path >= 0 && path <= 2, "engine_set_path: path must be 0 (auto), 1 (direct) or 2 (binned)");
+    e->forced_path = path;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out) {
+    PCR_REQUIRE(e && out, "engine_stats: null argument");
+    unsigned long long c[8] = {0};
+    PCR_HIP_TRY(hipMemcpyAsync(c, e->d_counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
+    PCR_HIP_TRY(hipStreamSynchronize(e->stream));
+    *out = e->stats;
+    out->points_valid = c[0];
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, int32_t* tiles_x, int32_t* tiles_y) {
+    PCR_REQUIRE(e && d_tile_touched, "engine_tile_touched: null argument");
+    *d_tile_touched = e->d_touched;
+    if (tiles_x) *tiles_x = e->gd.tiles_x;
+    if (tiles_y) *tiles_y = e->gd.tiles_y;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_planes* planes,
+                          const double* d_x, const double* d_y, const float* d_value, uint64_t n) {
+    PCR_REQUIRE(e, "scatter_point: null engine");
+    PlanesDev pl;
+    int rc = check_planes(plane_mask, planes, 15u, pl);
+    if (rc) return rc;
+    if (n == 0) return PCR_HIP_OK;                       // empty cloud is a no-op (pipeline.cpp:284-287)
+    PCR_REQUIRE(n < ((uint64_t)1 << 40), "scatter_point: too many points in one call");
+    PCR_REQUIRE(d_x && d_y, "scatter_point: null coordinate array");
+    PCR_REQUIRE(d_value || plane_mask == PCR_HIP_PLANE_WGT, "scatter_point: null value array");
+    rc = begin_scatter(e, n);
+    if (rc) return rc;
+    bool can_bin = binned_point_supported(e, plane_mask);
+    if (e->forced_path == 2 && !can_bin)
+        return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: binned path forced but not applicable to this grid");
+    if (e->forced_path == 2 || (e->forced_path == 0 && can_bin))
+        return binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    return direct_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+}
+
+int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_t plane_mask,
+                          const pcr_hip_planes* planes,
+                          const double* d_x, const double* d_y, const float* d_value, uint64_t n) {
+    PCR_REQUIRE(e && glyph, "scatter_glyph: null argument");
+    if (glyph->type == PCR_HIP_GLYPH_POINT)
+        return fail(PCR_HIP_INVALID_ARGUMENT, "accumulate_glyph: Point glyph should use regular accumulate()");
+    if (glyph->type != PCR_HIP_GLYPH_LINE && glyph->type != PCR_HIP_GLYPH_GAUSSIAN)
+        return fail(PCR_HIP_NOT_IMPLEMENTED, "glyph: unknown glyph type");
+    if (plane_mask & (PCR_HIP_PLANE_MAX | PCR_HIP_PLANE_MIN))
+        return fail(PCR_HIP_NOT_IMPLEMENTED,
+                    "glyph splatting only supports WeightedAverage, Average, Sum, or Count reduction types");
+    PlanesDev pl;
+    int rc = check_planes(plane_mask, planes, 3u, pl);
+    if (rc) return rc;
+    if (n == 0) return PCR_HIP_OK;
+    PCR_REQUIRE(n < ((uint64_t)1 << 40), "scatter_glyph: too many points in one call");
+    PCR_REQUIRE(d_x && d_y && d_value, "scatter_glyph: null point array");
+    GlyphDev gl;
+    gl.type = glyph->type;
+    gl.def_direction = glyph->default_direction;
+    gl.def_half_length = glyph->default_half_length;
+    gl.def_sigma_x = glyph->default_sigma_x;
+    gl.def_sigma_y = glyph->default_sigma_y;
+    gl.def_rotation = glyph->default_rotation;
+    gl.max_radius = glyph->max_radius_cells;
+    gl.direction = glyph->d_direction;
+    gl.half_length = glyph->d_half_length;
+    gl.sigma_x = glyph->d_sigma_x;
+    gl.sigma_y = glyph->d_sigma_y;
+    gl.rotation = glyph->d_rotation;
+    rc = begin_scatter(e, n);
+    if (rc) return rc;
+    bool can_bin = binned_glyph_supported(e, gl, plane_mask);
+    if (e->forced_path == 2 && !can_bin)
+        return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: binned path forced but not applicable");
+    if (e->forced_path == 2 || (e->forced_path == 0 && can_bin))
+        return binned_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    return direct_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// engine.hpp -- the scatter engine object behind pcr_hip_engine_* / pcr_hip_scatter_*.
+#pragma once
+
+#include "common.hpp"
+
+struct pcr_hip_engine {
+    pcr_hip_grid grid{};
+    pcrhip::GridDev gd{};
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int num_cus = 256;
+
+    uint32_t* d_touched = nullptr;             // tiles_x * tiles_y words
+    int ntiles = 0;
+    unsigned long long* d_counters = nullptr;  // [0] = valid points of the last scatter
+
+    int forced_path = 0;                       // 0 auto, 1 direct, 2 binned
+    pcr_hip_scatter_stats stats{};
+
+    // grow-only scratch for the binned path (bin counters, cursors, records)
+    char* d_scratch = nullptr;
+    size_t scratch_cap = 0;
+};
+
+namespace pcrhip {
+
+int ensure_scratch(pcr_hip_engine* e, size_t bytes);
+
+// direct path (global atomics), scatter_direct.hip
+int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
+                 const double* x, const double* y, const float* v, uint64_t n);
+int direct_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
+                 const double* x, const double* y, const float* v, uint64_t n);
+
+// binned path (LDS tiles), scatter_binned.hip
+bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask);
+int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
+                 const double* x, const double* y, const float* v, uint64_t n);
+bool binned_glyph_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);
+int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
+                 const double* x, const double* y, const float* v, uint64_t n);
+
+}  // namespace pcrhip

@@ -1,0 +1,161 @@
+// glyph_device.hpp -- in-register glyph footprints (Gaussian, Bresenham line), shared by the
+// direct (global atomics) and the binned (LDS tile) scatter kernels through a Sink:
+//     sink.add(row, col, v_times_w, w)        row/col are GLOBAL cell coordinates, already clipped
+//
+// Arithmetic follows the reference's CPU glyph code, NOT its CUDA kernels
+// (src/engine/glyph_kernels.cu:79-281): f64 fractional cell position via multiplication
+// by 1/cell_size, f32 sub-cell offsets and weights, footprint clipped to the reference tile
+// of the centre cell (quirk Q4), corner sampling (Q5), signed sigma_y (Q6), f64 line
+// end points rounded half away from zero (Q7).
+#pragma once
+
+#include "common.hpp"
+
+namespace pcrhip {
+
+// Per-point set-up shared by both glyphs: validity, centre cell, clip rectangle.
+struct PointGeom {
+    double fcx, fcy;      // fractional cell coordinates (glyph_kernels.cu:110-111, 219-220)
+    int col, row;         // centre cell from world_to_cell (decides the tile), clamped
+    int cx0, cx1, cy0, cy1;   // clip rectangle [cx0,cx1) x [cy0,cy1): centre tile ∩ state window
+    bool valid;
+};
+
+__device__ __forceinline__ PointGeom point_geom(const GridDev& g, double wx, double wy) {
+    PointGeom p;
+    p.valid = world_to_cell(g, wx, wy, p.col, p.row);
+    p.valid = p.valid && p.row >= g.own_r0 && p.row < g.own_r1;
+    p.fcx = (wx - g.min_x) * g.inv_csx;
+    p.fcy = (wy - g.max_y) * g.inv_csy;
+    int tcx = p.valid ? p.col / g.tw : 0, tcy = p.valid ? p.row / g.th : 0;
+    p.cx0 = tcx * g.tw;
+    p.cx1 = min(p.cx0 + g.tw, g.W);
+    p.cy0 = max(tcy * g.th, g.st_r0);
+    p.cy1 = min(min(tcy * g.th + g.th, g.H), g.st_r0 + g.st_rows);
+    return p;
+}
+
+// cosf/sinf as the host libm returns them: glibc's float routines evaluate in double and
+// round once, so (float)cos((double)a) reproduces them (differences would move a line's
+// rounded end point by a whole cell).
+__device__ __forceinline__ void sincos_like_libm(float a, float& s, float& c) {
+    double sd, cd;
+    sincos((double)a, &sd, &cd);
+    s = (float)sd;
+    c = (float)cd;
+}
+
+// ---- Gaussian ------------------------------------------------------------------
+struct GaussParams {
+    float val, sub_cx, sub_cy, sx, sy, cos_r, sin_r;
+    int icx, icy, r;
+    int cx0, cx1, cy0, cy1;
+};
+
+// glyph_kernels.cu:105-145 for the lane's own point.
+__device__ __forceinline__ GaussParams gauss_params(const GridDev& g, const GlyphDev& gl,
+                                                    const PointGeom& pg, float val, uint64_t i) {
+    GaussParams q;
+    q.val = val;
+    double flx = floor(pg.fcx), fly = floor(pg.fcy);
+    q.sub_cx = (float)(pg.fcx - flx);
+    q.sub_cy = (float)(pg.fcy - fly);
+    float sxw = gl.def_sigma_x, syw = gl.def_sigma_y;
+    if (gl.sigma_x) { float t = gl.sigma_x[i]; if (t > 0.0f) sxw = t; }
+    if (gl.sigma_y) { float t = gl.sigma_y[i]; if (t > 0.0f) syw = t; }
+    q.sx = sxw * (float)g.inv_csx;
+    q.sy = syw * (float)g.inv_csy;
+    float rot = gl.rotation ? gl.rotation[i] : gl.def_rotation;
+    sincos_like_libm(-rot, q.sin_r, q.cos_r);
+    float R = fminf(3.0f * fmaxf(q.sx, q.sy), gl.max_radius);
+    // a NaN/huge radius cannot run away: the clip rectangle bounds the loop below
+    q.r = min((int)ceilf(R), 1 << 20);
+    q.icx = (int)flx;
+    q.icy = (int)fly;
+    q.cx0 = pg.cx0; q.cx1 = pg.cx1; q.cy0 = pg.cy0; q.cy1 = pg.cy1;
+    return q;
+}
+
+// Weight of offset (dx, dy): glyph_kernels.cu:157-166.
+__device__ __forceinline__ float gauss_weight(const GaussParams& q, int dx, int dy) {
+    float rdx = (float)dx - q.sub_cx;
+    float rdy = (float)dy - q.sub_cy;
+    float rxr = rdx * q.cos_r + rdy * (-q.sin_r);
+    float ryr = rdx * q.sin_r + rdy * q.cos_r;
+    float a = rxr / q.sx, b = ryr / q.sy;
+    return expf(-0.5f * (a * a + b * b));
+}
+
+// One WAVE paints one point: the (2r+1)^2 window clipped to the clip rectangle is
+// enumerated row-major, 64 cells per step, so consecutive lanes hit consecutive cells
+// of a row (contiguous atomics).  q must be wave-uniform.
+template <typename Sink>
+__device__ __forceinline__ void gauss_splat_wave(const GaussParams& q, int lane, Sink& sink) {
+    // intersect the window with the clip rectangle first: no lane iterates outside it
+    int x0 = max(q.icx - q.r, q.cx0), x1 = min(q.icx + q.r + 1, q.cx1);
+    int y0 = max(q.icy - q.r, q.cy0), y1 = min(q.icy + q.r + 1, q.cy1);
+    int wdt = x1 - x0, hgt = y1 - y0;
+    if (wdt <= 0 || hgt <= 0) return;
+    int total = wdt * hgt;
+    float inv_w = 1.0f / (float)wdt;
+    const bool small = total < (1 << 18);                 // float row index exact below 2^21 cells
+    for (int idx = lane; idx < total; idx += 64) {
+        int ry = small ? (int)(((float)idx + 0.5f) * inv_w) : idx / wdt;
+        int rx = idx - ry * wdt;
+        int gx = x0 + rx, gy = y0 + ry;
+        float w = gauss_weight(q, gx - q.icx, gy - q.icy);
+        if (w < 1e-6f) continue;                          // glyph_kernels.cu:166
+        sink.add(gy, gx, q.val * w, w);
+    }
+}
+
+// ---- Line ------------------------------------------------------------------------
+struct LineParams {
+    float val;
+    int ix0, iy0, ix1, iy1;
+    int cx0, cx1, cy0, cy1;
+};
+
+// glyph_kernels.cu:213-250.
+__device__ __forceinline__ LineParams line_params(const GridDev& g, const GlyphDev& gl,
+                                                  const PointGeom& pg, float val, uint64_t i) {
+    LineParams q;
+    q.val = val;
+    float direction = gl.direction ? gl.direction[i] : gl.def_direction;
+    float half_len = gl.half_length ? gl.half_length[i] : gl.def_half_length;
+    float hx = half_len * (float)g.inv_csx;
+    float hy = half_len * (float)g.inv_csy;
+    hx = fminf(hx, gl.max_radius);                 // std::min(h, cap): hy < 0 is never capped (Q7)
+    hy = fminf(hy, gl.max_radius);
+    float sd, cd;
+    sincos_like_libm(direction, sd, cd);
+    float px = hx * cd, py = hy * sd;              // f32 products, then f64 sums (:240-243)
+    double x0 = pg.fcx - (double)px, y0 = pg.fcy - (double)py;
+    double x1 = pg.fcx + (double)px, y1 = pg.fcy + (double)py;
+    q.ix0 = (int)round(x0); q.iy0 = (int)round(y0);
+    q.ix1 = (int)round(x1); q.iy1 = (int)round(y1);
+    q.cx0 = pg.cx0; q.cx1 = pg.cx1; q.cy0 = pg.cy0; q.cy1 = pg.cy1;
+    return q;
+}
+
+// One LANE walks one segment (integer Bresenham, glyph_kernels.cu:252-278), weight 1 per cell.
+template <typename Sink>
+__device__ __forceinline__ void line_walk(const LineParams& q, Sink& sink) {
+    int ddx = abs(q.ix1 - q.ix0), ddy = abs(q.iy1 - q.iy0);
+    int sxs = q.ix0 < q.ix1 ? 1 : -1, sys = q.iy0 < q.iy1 ? 1 : -1;
+    int err = ddx - ddy, cx = q.ix0, cy = q.iy0;
+    // Deliberate divergence: a segment longer than 2^23 cells (a garbage half_length or
+    // direction) is dropped instead of being walked for minutes inside one lane.
+    long long bound = 2ll * ((long long)ddx + ddy) + 2;
+    if (ddx < 0 || ddy < 0 || bound > (1ll << 24)) return;
+    int max_steps = (int)bound;
+    for (int step = 0; step <= max_steps; ++step) {
+        if (cx >= q.cx0 && cx < q.cx1 && cy >= q.cy0 && cy < q.cy1) sink.add(cy, cx, q.val, 1.0f);
+        if (cx == q.ix1 && cy == q.iy1) break;
+        int e2 = 2 * err;
+        if (e2 > -ddy) { err -= ddy; cx += sxs; }
+        if (e2 < ddx) { err += ddx; cy += sys; }
+    }
+}
+
+}  // namespace pcrhip

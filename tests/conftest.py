@@ -55,3 +55,16 @@ def assert_band_close(got, want, rtol=0.0, atol=0.0, what=""):
         bad = np.abs(g - w) > atol + rtol * np.abs(w)
     assert not bad.any(), (f"{what}: {int(bad.sum())} cells differ, max abs err "
                            f"{float(np.max(np.abs(g - w)))}")
+
+
+def load_cabi():
+    """The ctypes view of the C-ABI (pcr/_cabi.py), loaded without importing the pybind module."""
+    import importlib.util
+    name = "pcr_cabi_standalone"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(PKG_PY, "pcr", "_cabi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
