@@ -173,6 +173,17 @@ int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
 /* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */
 int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, int32_t* tiles_x, int32_t* tiles_y);
 
+/* Per-kernel timing with HIP events on the engine's stream (for roofline reporting).
+ * While enabled every kernel the engine launches is bracketed by two events; _read drains the
+ * events (synchronizes) and returns, per kernel name, launches and summed milliseconds. */
+typedef struct pcr_hip_kernel_time {
+    char name[48];
+    uint32_t launches;
+    double total_ms;
+} pcr_hip_kernel_time;
+int pcr_hip_engine_profile_enable(pcr_hip_engine* e, int on);
+int pcr_hip_engine_profile_read(pcr_hip_engine* e, pcr_hip_kernel_time* out, int capacity, int* count, int reset);
+
 /* Point glyph: every valid point folds `value` into the planes named by plane_mask at its cell.
  * d_value may be NULL only when plane_mask == PCR_HIP_PLANE_WGT. */
 int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_planes* planes,

@@ -89,6 +89,7 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
 int pcr_hip_engine_destroy(pcr_hip_engine* e) {
     if (!e) return PCR_HIP_OK;
     (void)hipStreamSynchronize(e->stream);
+    for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (e->d_touched) (void)hipFree(e->d_touched);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
@@ -118,6 +119,41 @@ int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, in
     *d_tile_touched = e->d_touched;
     if (tiles_x) *tiles_x = e->gd.tiles_x;
     if (tiles_y) *tiles_y = e->gd.tiles_y;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_profile_enable(pcr_hip_engine* e, int on) {
+    PCR_REQUIRE(e, "engine_profile_enable: null engine");
+    e->profiling = on != 0;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_profile_read(pcr_hip_engine* e, pcr_hip_kernel_time* out, int capacity, int* count, int reset) {
+    PCR_REQUIRE(e && count, "engine_profile_read: null argument");
+    for (auto& p : e->pending) {
+        float ms = 0.0f;
+        hipError_t err = hipEventSynchronize(p.b);
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, p.a, p.b);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+        if (err == hipSuccess) {
+            auto& slot = e->kernel_ms[p.name];
+            slot.first += 1;
+            slot.second += ms;
+        }
+    }
+    e->pending.clear();
+    int n = 0;
+    for (const auto& kv : e->kernel_ms) {
+        if (out && n < capacity) {
+            std::snprintf(out[n].name, sizeof out[n].name, "%s", kv.first.c_str());
+            out[n].launches = kv.second.first;
+            out[n].total_ms = kv.second.second;
+        }
+        ++n;
+    }
+    *count = n;
+    if (reset) e->kernel_ms.clear();
     return PCR_HIP_OK;
 }
 

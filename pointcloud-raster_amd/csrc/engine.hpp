@@ -3,6 +3,9 @@
 
 #include "common.hpp"
 
+#include <map>
+#include <vector>
+
 struct pcr_hip_engine {
     pcr_hip_grid grid{};
     pcrhip::GridDev gd{};
@@ -17,6 +20,12 @@ struct pcr_hip_engine {
     int forced_path = 0;                       // 0 auto, 1 direct, 2 binned
     pcr_hip_scatter_stats stats{};
 
+    // optional per-kernel event timing
+    bool profiling = false;
+    struct Pending { const char* name; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::map<std::string, std::pair<uint32_t, double>> kernel_ms;
+
     // grow-only scratch for the binned path (bin counters, cursors, records)
     char* d_scratch = nullptr;
     size_t scratch_cap = 0;
@@ -25,6 +34,23 @@ struct pcr_hip_engine {
 namespace pcrhip {
 
 int ensure_scratch(pcr_hip_engine* e, size_t bytes);
+
+// Brackets one kernel launch with events when profiling is on.
+struct ScopedKernelTimer {
+    pcr_hip_engine* e;
+    const char* name;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTimer(pcr_hip_engine* eng, const char* nm) : e(eng), name(nm) {
+        if (!e->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, e->stream);
+    }
+    ~ScopedKernelTimer() {
+        if (!a) return;
+        (void)hipEventRecord(b, e->stream);
+        e->pending.push_back({name, a, b});
+    }
+};
 
 // direct path (global atomics), scatter_direct.hip
 int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,

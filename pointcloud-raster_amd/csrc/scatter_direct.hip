@@ -151,6 +151,7 @@ namespace pcrhip {
 int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n) {
     int blocks = blocks_for(n, 8, e->num_cus);
+    ScopedKernelTimer t(e, "k_point_direct");
     switch (mask) {
         PCR_DISPATCH_POINT_MASK(1)  PCR_DISPATCH_POINT_MASK(2)  PCR_DISPATCH_POINT_MASK(3)
         PCR_DISPATCH_POINT_MASK(4)  PCR_DISPATCH_POINT_MASK(5)  PCR_DISPATCH_POINT_MASK(6)
@@ -168,6 +169,7 @@ int direct_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
                  const double* x, const double* y, const float* v, uint64_t n) {
     if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
         // one wave per 64-point batch; keep every CU busy with 8 blocks
+        ScopedKernelTimer t(e, "k_gauss_direct");
         uint64_t batches = (n + 63) / 64;
         int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((batches + 3) / 4, (uint64_t)8 * e->num_cus));
         switch (mask) {
@@ -177,6 +179,7 @@ int direct_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
             default: return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: plane mask must be SUM and/or WGT");
         }
     } else if (gl.type == PCR_HIP_GLYPH_LINE) {
+        ScopedKernelTimer t(e, "k_line_direct");
         int blocks = blocks_for(n, 8, e->num_cus);
         switch (mask) {
             case 1: hipLaunchKernelGGL((k_line_direct<1>), dim3(blocks), dim3(kBlock), 0, e->stream, e->gd, gl, pl, x, y, v, n, e->d_touched, e->d_counters); break;

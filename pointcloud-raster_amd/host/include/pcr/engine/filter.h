@@ -1,0 +1,46 @@
+// pcr/engine/filter.h -- point filter specification (API parity with the reference's
+// include/pcr/engine/filter.h).  The filter stage itself is outside the accelerated path of
+// this build: a pipeline configured with a non-empty FilterSpec refuses to ingest.
+#pragma once
+
+#include "pcr/core/types.h"
+
+#include <string>
+#include <vector>
+
+namespace pcr {
+
+enum class CompareOp : uint8_t {
+    Equal, NotEqual, Less, LessEqual, Greater, GreaterEqual, InSet, NotInSet
+};
+
+struct FilterPredicate {
+    std::string channel_name;
+    CompareOp op = CompareOp::Equal;
+    float value = 0.0f;
+    std::vector<float> value_set;
+};
+
+struct FilterSpec {
+    std::vector<FilterPredicate> predicates;
+
+    FilterSpec& add(const std::string& channel, CompareOp op, float value) {
+        FilterPredicate p;
+        p.channel_name = channel;
+        p.op = op;
+        p.value = value;
+        predicates.push_back(p);
+        return *this;
+    }
+    FilterSpec& add_in_set(const std::string& channel, const std::vector<float>& values) {
+        FilterPredicate p;
+        p.channel_name = channel;
+        p.op = CompareOp::InSet;
+        p.value_set = values;
+        predicates.push_back(p);
+        return *this;
+    }
+    bool empty() const { return predicates.empty(); }
+};
+
+}  // namespace pcr

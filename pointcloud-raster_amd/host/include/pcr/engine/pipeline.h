@@ -1,0 +1,128 @@
+// pcr/engine/pipeline.h -- the public engine API (drop-in for the reference's
+// include/pcr/engine/pipeline.h:20-145): ReductionSpec, ExecutionMode, PipelineConfig,
+// ProgressInfo, Pipeline{create, validate, ingest, finalize, run, set_progress_callback,
+// result, stats}.  Behind it: the MI355X HIP engine (include/pcr_hip.h).  There is no CPU
+// engine in this build: ExecutionMode::CPU, a missing GPU or a failing HIP call are errors,
+// never a silent fallback.
+#pragma once
+
+#include "pcr/core/grid_config.h"
+#include "pcr/core/types.h"
+#include "pcr/engine/filter.h"
+#include "pcr/engine/glyph.h"
+
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace pcr {
+
+class PointCloud;
+class Grid;
+
+struct ReductionSpec {
+    std::string value_channel;
+    ReductionType type = ReductionType::Sum;
+    std::string weight_channel;        // declared; WeightedAverage uses weight 1 with the Point glyph (reference behaviour)
+    std::string timestamp_channel;
+    float percentile = 0.5f;
+    std::string output_band_name;      // default "{value_channel}_{int(type)}"
+    GlyphSpec glyph;
+};
+
+enum class ExecutionMode : uint8_t { CPU, GPU, Auto, Hybrid };
+
+struct PipelineConfig {
+    GridConfig grid;
+    std::vector<ReductionSpec> reductions;
+    FilterSpec filter;
+
+    CRS target_crs;
+    bool auto_reproject = true;
+
+    ExecutionMode exec_mode = ExecutionMode::Auto;   // GPU, Auto and Hybrid all run the HIP engine
+
+    size_t gpu_memory_budget = 0;
+    size_t host_cache_budget = 0;
+    size_t chunk_size = 0;
+
+    size_t gpu_pool_size_bytes = 512 * 1024 * 1024;  // initial scratch arena of the engine
+    int cuda_device_id = 0;                          // HIP device ordinal
+    bool use_cuda_streams = true;
+    bool gpu_fallback_to_cpu = true;                 // ignored: no CPU engine to fall back to
+    bool gpu_require_strict = false;
+
+    size_t cpu_threads = 0;
+    size_t hybrid_cpu_threads = 0;
+
+    std::string state_dir;
+    bool resume = false;
+
+    std::string output_path;                         // GeoTIFF writing is not part of this build
+    bool write_cog = false;
+
+    // ---- extensions (not in the reference; defaults keep reference behaviour) ----------
+    MemoryLocation result_location = MemoryLocation::Host;   // Device: finalize() leaves bands in HBM
+    // Row-block sharding of the grid over GPUs: this pipeline ingests points whose centre row
+    // is in [shard_row_begin, shard_row_end) and finalizes those rows; -1 = whole grid.
+    int shard_row_begin = -1;
+    int shard_row_end = -1;
+    int scatter_path = 0;                            // 0 auto, 1 direct atomics, 2 binned LDS tiles
+};
+
+struct ProgressInfo {
+    size_t collections_processed = 0;
+    size_t collections_total = 0;
+    size_t points_processed = 0;
+    size_t tiles_active = 0;
+    float elapsed_seconds = 0.0f;
+};
+
+using ProgressCallback = std::function<bool(const ProgressInfo& info)>;
+
+class Pipeline {
+public:
+    ~Pipeline();
+
+    static std::unique_ptr<Pipeline> create(const PipelineConfig& config);   // nullptr on failure
+
+    Status validate() const;
+    Status ingest(const PointCloud& cloud);
+    Status finalize();
+    Status run(const std::vector<const PointCloud*>& clouds);
+    void set_progress_callback(ProgressCallback cb);
+    const Grid* result() const;
+    ProgressInfo stats() const;
+
+    // ---- extensions for row-block sharded runs (halo exchange is driven by the caller,
+    //      e.g. torch.distributed over RCCL: see pcr/distributed.py) -------------------------
+    struct PlaneView {
+        void* device_ptr;      // first float of the plane (row state_row_begin)
+        int plane_kind;        // PCR_HIP_PLANE_* of include/pcr_hip.h
+        int group;             // accumulation group index
+    };
+    int halo_rows() const;                       // rows kept above/below the owned block
+    int state_row_begin() const;
+    int state_row_count() const;
+    std::vector<PlaneView> state_planes() const;
+    void* tile_touched_device(int* tiles_x, int* tiles_y) const;
+    Status synchronize();
+    // per-kernel HIP-event timing of the scatter kernels (roofline reporting)
+    struct KernelTime { std::string name; unsigned launches; double total_ms; };
+    void profile_enable(bool on);
+    std::vector<KernelTime> profile_read(bool reset);
+    // path and LDS tiling the last scatter used (0 direct, 1 binned), exact valid-point count
+    struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; };
+    ScatterInfo last_scatter() const;
+
+private:
+    Pipeline() = default;
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// Why the last Pipeline::create() on this thread returned nullptr.
+const std::string& pipeline_create_error();
+
+}  // namespace pcr

@@ -1,0 +1,482 @@
+// pipeline.cpp -- Pipeline::{create, ingest, finalize, ...}: host orchestration of the HIP engine.
+//
+// Same observable contract as the reference's src/engine/pipeline.cpp (validation and error
+// strings :365-378, 500-508; empty cloud no-op :284-287; per-ingest progress callback and
+// "cancelled by user" :753-767; band naming :1175-1186; NaN for untouched tiles :1204-1222;
+// state survives finalize), but a different machine underneath:
+//   * no router / sort / per-tile batches / tile manager: reductions that read the same value
+//     channel through the same glyph share ONE pass over the points and ONE set of device
+//     planes (sum, weight, max, min) in grid layout, resident in HBM for the pipeline's life;
+//   * finalize runs on the device; only finalized bands cross PCIe (or stay in HBM);
+//   * every device action goes through the C-ABI of include/pcr_hip.h.
+#include "pcr/engine/pipeline.h"
+
+#include "buffer.h"
+#include "pcr/core/grid.h"
+#include "pcr/core/point_cloud.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <map>
+
+namespace pcr {
+
+namespace {
+
+thread_local std::string g_create_error;
+
+bool registered(ReductionType t) {
+    switch (t) {
+        case ReductionType::Sum: case ReductionType::Max: case ReductionType::Min:
+        case ReductionType::Average: case ReductionType::WeightedAverage: case ReductionType::Count:
+            return true;
+        default:
+            return false;
+    }
+}
+
+bool glyph_reduction_ok(ReductionType t) {
+    return t == ReductionType::WeightedAverage || t == ReductionType::Average ||
+           t == ReductionType::Sum || t == ReductionType::Count;
+}
+
+uint32_t planes_for(ReductionType t) {
+    switch (t) {
+        case ReductionType::Sum: return PCR_HIP_PLANE_SUM;
+        case ReductionType::Count: return PCR_HIP_PLANE_WGT;
+        case ReductionType::Max: return PCR_HIP_PLANE_MAX;
+        case ReductionType::Min: return PCR_HIP_PLANE_MIN;
+        default: return PCR_HIP_PLANE_SUM | PCR_HIP_PLANE_WGT;      // Average, WeightedAverage
+    }
+}
+
+bool same_glyph(const GlyphSpec& a, const GlyphSpec& b) {
+    if (a.type != b.type) return false;
+    if (a.type == GlyphType::Point) return true;
+    return a.direction_channel == b.direction_channel && a.default_direction == b.default_direction &&
+           a.half_length_channel == b.half_length_channel && a.default_half_length == b.default_half_length &&
+           a.sigma_x_channel == b.sigma_x_channel && a.default_sigma_x == b.default_sigma_x &&
+           a.sigma_y_channel == b.sigma_y_channel && a.default_sigma_y == b.default_sigma_y &&
+           a.rotation_channel == b.rotation_channel && a.default_rotation == b.default_rotation &&
+           a.max_radius_cells == b.max_radius_cells;
+}
+
+constexpr uint32_t kPlaneBits[4] = {PCR_HIP_PLANE_SUM, PCR_HIP_PLANE_WGT, PCR_HIP_PLANE_MAX, PCR_HIP_PLANE_MIN};
+
+}  // namespace
+
+const std::string& pipeline_create_error() { return g_create_error; }
+
+struct Pipeline::Impl {
+    struct Group {                       // one pass over the points
+        std::string value_channel;
+        GlyphSpec glyph;
+        uint32_t mask = 0;
+        detail::Buffer planes[4];
+        pcr_hip_planes view{};
+    };
+    struct Output {                      // one ReductionSpec -> one band
+        int group = 0;
+        ReductionType type = ReductionType::Sum;
+        std::string band_name;
+    };
+
+    PipelineConfig cfg;
+    ProgressCallback callback;
+    pcr_hip_grid hg{};
+    pcr_hip_engine* engine = nullptr;
+    pcr_hip_stream stream = nullptr;
+    bool own_stream = false;
+    std::vector<Group> groups;
+    std::vector<Output> outputs;
+    std::vector<detail::Buffer> d_bands;     // finalized bands on the device (result_location == Host)
+    std::unique_ptr<Grid> result;
+    std::map<std::string, detail::Buffer> staging;   // device copies of host-resident arrays, grow-only
+    int halo = 0;
+    size_t collections = 0;
+    size_t points = 0;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+
+    ~Impl() {
+        if (engine) pcr_hip_engine_destroy(engine);
+        groups.clear();
+        d_bands.clear();
+        staging.clear();
+        result.reset();
+        if (own_stream && stream) pcr_hip_stream_destroy(stream);
+    }
+
+    int own_rows() const { return hg.own_row1 - hg.own_row0; }
+
+    Status init() {
+        const GridConfig& g = cfg.grid;
+        if (cfg.exec_mode == ExecutionMode::CPU)
+            return Status::error(StatusCode::NotImplemented,
+                "pipeline: ExecutionMode::CPU is not available: this build contains only the MI355X HIP engine "
+                "(use GPU or Auto)");
+        if (g.width <= 0 || g.height <= 0)
+            return Status::error(StatusCode::InvalidArgument, "pipeline: grid dimensions must be positive");
+        if (g.tile_width <= 0 || g.tile_height <= 0)
+            return Status::error(StatusCode::InvalidArgument, "pipeline: tile dimensions must be positive");
+        for (const auto& r : cfg.reductions)
+            if (!registered(r.type))
+                return Status::error(StatusCode::InvalidArgument, "pipeline: unknown reduction type");
+
+        int ndev = 0;
+        pcr_hip_device_count(&ndev);
+        if (ndev <= 0)
+            return Status::error(StatusCode::CudaError,
+                "pipeline: no HIP device available (and no CPU engine to fall back to)");
+        if (cfg.cuda_device_id < 0 || cfg.cuda_device_id >= ndev)
+            return Status::error(StatusCode::InvalidArgument, "pipeline: invalid device id");
+        Status s = detail::hip_status(pcr_hip_set_device(cfg.cuda_device_id));
+        if (!s.ok()) return s;
+        if (cfg.use_cuda_streams) {
+            s = detail::hip_status(pcr_hip_stream_create(&stream));
+            if (!s.ok()) return s;
+            own_stream = true;
+        }
+
+        // accumulation groups + outputs
+        for (const auto& r : cfg.reductions) {
+            int gi = -1;
+            for (size_t k = 0; k < groups.size(); ++k)
+                if (groups[k].value_channel == r.value_channel && same_glyph(groups[k].glyph, r.glyph)) gi = (int)k;
+            if (gi < 0) {
+                groups.emplace_back();
+                gi = (int)groups.size() - 1;
+                groups[gi].value_channel = r.value_channel;
+                groups[gi].glyph = r.glyph;
+            }
+            // a glyph reduction of an unsupported type is rejected at ingest (as in the reference);
+            // it still gets planes so that finalize has something to read.
+            groups[gi].mask |= planes_for(r.type);
+            Output o;
+            o.group = gi;
+            o.type = r.type;
+            o.band_name = r.output_band_name.empty()
+                ? r.value_channel + "_" + std::to_string(static_cast<int>(r.type)) : r.output_band_name;
+            outputs.push_back(o);
+        }
+
+        // row window of this device
+        int r0 = 0, r1 = g.height;
+        if (cfg.shard_row_begin >= 0 || cfg.shard_row_end >= 0) {
+            r0 = cfg.shard_row_begin < 0 ? 0 : cfg.shard_row_begin;
+            r1 = cfg.shard_row_end < 0 ? g.height : cfg.shard_row_end;
+            if (r0 > r1 || r1 > g.height)
+                return Status::error(StatusCode::InvalidArgument, "pipeline: shard row range outside the grid");
+            for (const auto& gr : groups) halo = std::max(halo, reach_rows(gr.glyph));
+            halo = std::min(halo, g.height);
+        }
+        hg.min_x = g.bounds.min_x; hg.min_y = g.bounds.min_y; hg.max_x = g.bounds.max_x; hg.max_y = g.bounds.max_y;
+        hg.cell_size_x = g.cell_size_x; hg.cell_size_y = g.cell_size_y;
+        hg.width = g.width; hg.height = g.height;
+        hg.tile_width = g.tile_width; hg.tile_height = g.tile_height;
+        hg.own_row0 = r0; hg.own_row1 = r1;
+        hg.state_row0 = std::max(0, r0 - halo);
+        hg.state_rows = std::min(g.height, r1 + halo) - hg.state_row0;
+
+        s = detail::hip_status(pcr_hip_engine_create(&engine, &hg, 0, stream));
+        if (!s.ok()) return s;
+        s = detail::hip_status(pcr_hip_engine_set_path(engine, cfg.scatter_path));
+        if (!s.ok()) return s;
+
+        const int64_t cells = (int64_t)hg.state_rows * hg.width;
+        for (auto& gr : groups) {
+            for (int p = 0; p < 4; ++p) {
+                if (!(gr.mask & kPlaneBits[p])) continue;
+                s = gr.planes[p].allocate((size_t)std::max<int64_t>(cells, 1) * sizeof(float), MemoryLocation::Device);
+                if (!s.ok()) return s;
+                float ident = p == 2 ? -3.402823466e+38f : p == 3 ? 3.402823466e+38f : 0.0f;
+                s = detail::hip_status(pcr_hip_plane_fill(static_cast<float*>(gr.planes[p].data()), ident, cells, stream));
+                if (!s.ok()) return s;
+            }
+            gr.view.d_sum = static_cast<float*>(gr.planes[0].data());
+            gr.view.d_wgt = static_cast<float*>(gr.planes[1].data());
+            gr.view.d_max = static_cast<float*>(gr.planes[2].data());
+            gr.view.d_min = static_cast<float*>(gr.planes[3].data());
+        }
+        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    }
+
+    // rows a glyph can reach above/below its centre row (sizes the halo of a row-block shard)
+    int reach_rows(const GlyphSpec& gl) const {
+        double cap = std::min<double>(std::max(0.0f, gl.max_radius_cells), 1 << 20);
+        if (gl.type == GlyphType::Gaussian) return (int)std::ceil(cap);
+        if (gl.type == GlyphType::Line) {
+            double hy = std::fabs((double)gl.default_half_length / cfg.grid.cell_size_y);
+            return (int)std::ceil(std::max(hy, cap)) + 1;
+        }
+        return 0;
+    }
+
+    // Device pointer of a named array of the cloud; host-resident arrays are staged to HBM.
+    Status device_array(const void* src, MemoryLocation loc, size_t bytes, const std::string& key,
+                        const void** out) {
+        if (loc == MemoryLocation::Device) { *out = src; return Status::success(); }
+        detail::Buffer& b = staging[key];
+        if (b.bytes() < bytes) {
+            // earlier kernels may still read the old block
+            Status s = detail::hip_status(pcr_hip_stream_synchronize(stream));
+            if (!s.ok()) return s;
+            s = b.allocate(bytes + bytes / 8, MemoryLocation::Device);
+            if (!s.ok()) return s;
+        }
+        Status s = detail::hip_status(pcr_hip_memcpy_h2d(b.data(), src, bytes, stream));
+        if (!s.ok()) return s;
+        *out = b.data();
+        return Status::success();
+    }
+
+    Status ingest(const PointCloud& cloud) {
+        const size_t n = cloud.count();
+        if (n == 0) return Status::success();
+        if (!cfg.filter.empty())
+            return Status::error(StatusCode::NotImplemented,
+                "pipeline: FilterSpec is not supported by this build (filter stage is outside the accelerated path)");
+
+        // validate every reduction before touching state
+        for (const auto& r : cfg.reductions) {
+            if (!cloud.channel_data(r.value_channel))
+                return Status::error(StatusCode::InvalidArgument,
+                                     "pipeline: value channel not found: " + r.value_channel);
+            const ChannelDesc* d = cloud.channel(r.value_channel);
+            if (!d || d->dtype != DataType::Float32)
+                return Status::error(StatusCode::InvalidArgument, "pipeline: value channel must be Float32");
+            if (r.glyph.type != GlyphType::Point && !glyph_reduction_ok(r.type))
+                return Status::error(StatusCode::NotImplemented,
+                    "pipeline: glyph splatting only supports WeightedAverage, Average, Sum, or Count reduction types");
+        }
+
+        const MemoryLocation loc = cloud.location();
+        const void *dx = nullptr, *dy = nullptr;
+        Status s = device_array(cloud.x(), loc, n * sizeof(double), "x", &dx);
+        if (!s.ok()) return s;
+        s = device_array(cloud.y(), loc, n * sizeof(double), "y", &dy);
+        if (!s.ok()) return s;
+
+        auto f32_channel = [&](const std::string& name, const void** out) -> Status {
+            *out = nullptr;
+            if (name.empty()) return Status::success();
+            const ChannelDesc* d = cloud.channel(name);
+            if (!d || d->dtype != DataType::Float32) return Status::success();   // -> GlyphSpec default
+            return device_array(cloud.channel_data(name), loc, n * sizeof(float), "ch:" + name, out);
+        };
+
+        for (auto& gr : groups) {
+            const void* dv = nullptr;
+            s = f32_channel(gr.value_channel, &dv);
+            if (!s.ok()) return s;
+            if (gr.glyph.type == GlyphType::Point) {
+                s = detail::hip_status(pcr_hip_scatter_point(
+                    engine, gr.mask, &gr.view, static_cast<const double*>(dx), static_cast<const double*>(dy),
+                    static_cast<const float*>(dv), n));
+            } else {
+                pcr_hip_glyph hgph{};
+                hgph.type = static_cast<int32_t>(gr.glyph.type);
+                hgph.default_direction = gr.glyph.default_direction;
+                hgph.default_half_length = gr.glyph.default_half_length;
+                hgph.default_sigma_x = gr.glyph.default_sigma_x;
+                hgph.default_sigma_y = gr.glyph.default_sigma_y;
+                hgph.default_rotation = gr.glyph.default_rotation;
+                hgph.max_radius_cells = gr.glyph.max_radius_cells;
+                const void* p = nullptr;
+                if (!(s = f32_channel(gr.glyph.direction_channel, &p)).ok()) return s;
+                hgph.d_direction = static_cast<const float*>(p);
+                if (!(s = f32_channel(gr.glyph.half_length_channel, &p)).ok()) return s;
+                hgph.d_half_length = static_cast<const float*>(p);
+                if (!(s = f32_channel(gr.glyph.sigma_x_channel, &p)).ok()) return s;
+                hgph.d_sigma_x = static_cast<const float*>(p);
+                if (!(s = f32_channel(gr.glyph.sigma_y_channel, &p)).ok()) return s;
+                hgph.d_sigma_y = static_cast<const float*>(p);
+                if (!(s = f32_channel(gr.glyph.rotation_channel, &p)).ok()) return s;
+                hgph.d_rotation = static_cast<const float*>(p);
+                s = detail::hip_status(pcr_hip_scatter_glyph(
+                    engine, &hgph, gr.mask & (PCR_HIP_PLANE_SUM | PCR_HIP_PLANE_WGT), &gr.view,
+                    static_cast<const double*>(dx), static_cast<const double*>(dy),
+                    static_cast<const float*>(dv), n));
+            }
+            if (!s.ok()) return s;
+        }
+        // host arrays may be reused by the caller as soon as we return
+        if (loc != MemoryLocation::Device) {
+            s = detail::hip_status(pcr_hip_stream_synchronize(stream));
+            if (!s.ok()) return s;
+        }
+
+        points += n;
+        collections++;
+        if (callback) {
+            ProgressInfo info = stats();
+            if (!callback(info))
+                return Status::error(StatusCode::InvalidArgument, "pipeline: cancelled by user");
+        }
+        return Status::success();
+    }
+
+    Status finalize() {
+        const int rows = own_rows();
+        const int W = hg.width;
+        std::vector<BandDesc> bands;
+        for (const auto& o : outputs) {
+            BandDesc b;
+            b.name = o.band_name;
+            b.dtype = DataType::Float32;
+            b.is_state = false;
+            bands.push_back(b);
+        }
+        if (bands.empty() || rows <= 0) {
+            result.reset();
+            return bands.empty() ? Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid")
+                                 : Status::success();
+        }
+        const bool on_device = cfg.result_location == MemoryLocation::Device;
+        if (!result) {
+            result = on_device ? Grid::create(W, rows, bands, MemoryLocation::Device)
+                               : Grid::create_host_page_locked(W, rows, bands);
+            if (!result) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
+            if (!on_device) {
+                d_bands.resize(outputs.size());
+                for (auto& b : d_bands) {
+                    Status s = b.allocate((size_t)rows * W * sizeof(float), MemoryLocation::Device);
+                    if (!s.ok()) return s;
+                }
+            }
+        }
+        uint32_t* d_touched = nullptr;
+        Status s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, nullptr, nullptr));
+        if (!s.ok()) return s;
+        for (size_t r = 0; r < outputs.size(); ++r) {
+            float* dst = on_device ? result->band_f32((int)r) : static_cast<float*>(d_bands[r].data());
+            s = detail::hip_status(pcr_hip_finalize(static_cast<int>(outputs[r].type), &hg,
+                                                    &groups[outputs[r].group].view, d_touched, dst, stream));
+            if (!s.ok()) return s;
+            if (!on_device) {
+                s = detail::hip_status(pcr_hip_memcpy_d2h(result->band_f32((int)r), dst,
+                                                          (size_t)rows * W * sizeof(float), stream));
+                if (!s.ok()) return s;
+            }
+        }
+        s = detail::hip_status(pcr_hip_stream_synchronize(stream));
+        if (!s.ok()) return s;
+        if (!cfg.output_path.empty())
+            return Status::error(StatusCode::NotImplemented,
+                "pipeline: output_path is set but GeoTIFF writing is not part of this build "
+                "(the finalized grid is available through result())");
+        return Status::success();
+    }
+
+    ProgressInfo stats() const {
+        ProgressInfo info;
+        info.collections_processed = collections;
+        info.collections_total = 0;
+        info.points_processed = points;
+        info.tiles_active = 0;
+        uint32_t* d_touched = nullptr;
+        int tx = 0, ty = 0;
+        if (engine && pcr_hip_engine_tile_touched(engine, &d_touched, &tx, &ty) == PCR_HIP_OK) {
+            std::vector<uint32_t> h((size_t)tx * ty);
+            if (pcr_hip_memcpy_d2h(h.data(), d_touched, h.size() * sizeof(uint32_t), stream) == PCR_HIP_OK &&
+                pcr_hip_stream_synchronize(stream) == PCR_HIP_OK)
+                for (uint32_t v : h) info.tiles_active += v ? 1 : 0;
+        }
+        info.elapsed_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+        return info;
+    }
+};
+
+Pipeline::~Pipeline() = default;
+
+std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
+    auto p = std::unique_ptr<Pipeline>(new Pipeline());
+    p->impl_ = std::make_unique<Impl>();
+    p->impl_->cfg = config;
+    Status s = p->impl_->init();
+    if (!s.ok()) {
+        g_create_error = s.message;
+        std::fprintf(stderr, "Error: %s\n", s.message.c_str());    // loud: there is no fallback path
+        return nullptr;
+    }
+    g_create_error.clear();
+    return p;
+}
+
+Status Pipeline::validate() const {
+    const PipelineConfig& c = impl_->cfg;
+    if (c.grid.width <= 0 || c.grid.height <= 0)
+        return Status::error(StatusCode::InvalidArgument, "pipeline: grid dimensions must be positive");
+    if (c.grid.tile_width <= 0 || c.grid.tile_height <= 0)
+        return Status::error(StatusCode::InvalidArgument, "pipeline: tile dimensions must be positive");
+    if (c.reductions.empty())
+        return Status::error(StatusCode::InvalidArgument, "pipeline: at least one reduction must be specified");
+    for (const auto& r : c.reductions) {
+        if (r.value_channel.empty())
+            return Status::error(StatusCode::InvalidArgument, "pipeline: value_channel must be specified");
+        if (!registered(r.type))
+            return Status::error(StatusCode::InvalidArgument, "pipeline: unknown reduction type");
+    }
+    return Status::success();
+}
+
+Status Pipeline::ingest(const PointCloud& cloud) { return impl_->ingest(cloud); }
+Status Pipeline::finalize() { return impl_->finalize(); }
+
+Status Pipeline::run(const std::vector<const PointCloud*>& clouds) {
+    for (const PointCloud* c : clouds) {
+        if (!c) return Status::error(StatusCode::InvalidArgument, "pipeline: null cloud pointer");
+        Status s = ingest(*c);
+        if (!s.ok()) return s;
+    }
+    return finalize();
+}
+
+void Pipeline::set_progress_callback(ProgressCallback cb) { impl_->callback = std::move(cb); }
+const Grid* Pipeline::result() const { return impl_->result.get(); }
+ProgressInfo Pipeline::stats() const { return impl_->stats(); }
+
+int Pipeline::halo_rows() const { return impl_->halo; }
+int Pipeline::state_row_begin() const { return impl_->hg.state_row0; }
+int Pipeline::state_row_count() const { return impl_->hg.state_rows; }
+
+std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
+    std::vector<PlaneView> out;
+    for (size_t g = 0; g < impl_->groups.size(); ++g)
+        for (int p = 0; p < 4; ++p)
+            if (impl_->groups[g].mask & kPlaneBits[p])
+                out.push_back({impl_->groups[g].planes[p].data(), (int)kPlaneBits[p], (int)g});
+    return out;
+}
+
+void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
+    uint32_t* d = nullptr;
+    int32_t tx = 0, ty = 0;
+    if (pcr_hip_engine_tile_touched(impl_->engine, &d, &tx, &ty) != PCR_HIP_OK) return nullptr;
+    if (tiles_x) *tiles_x = tx;
+    if (tiles_y) *tiles_y = ty;
+    return d;
+}
+
+Status Pipeline::synchronize() { return detail::hip_status(pcr_hip_stream_synchronize(impl_->stream)); }
+
+void Pipeline::profile_enable(bool on) { pcr_hip_engine_profile_enable(impl_->engine, on ? 1 : 0); }
+
+std::vector<Pipeline::KernelTime> Pipeline::profile_read(bool reset) {
+    std::vector<KernelTime> out;
+    pcr_hip_kernel_time buf[32];
+    int n = 0;
+    if (pcr_hip_engine_profile_read(impl_->engine, buf, 32, &n, reset ? 1 : 0) != PCR_HIP_OK) return out;
+    for (int i = 0; i < std::min(n, 32); ++i) out.push_back({buf[i].name, buf[i].launches, buf[i].total_ms});
+    return out;
+}
+
+Pipeline::ScatterInfo Pipeline::last_scatter() const {
+    pcr_hip_scatter_stats st{};
+    pcr_hip_engine_stats(impl_->engine, &st);
+    return {st.path, st.lds_tile_w, st.lds_tile_h, st.lds_apron, st.num_bins,
+            (size_t)st.points_in, (size_t)st.points_valid};
+}
+
+}  // namespace pcr

@@ -1,0 +1,161 @@
+// bind_engine.cpp -- FilterSpec, GlyphSpec, ReductionSpec, PipelineConfig, ProgressInfo, Pipeline.
+#include "common.h"
+
+#include "pcr/core/grid.h"
+#include "pcr/core/point_cloud.h"
+#include "pcr/engine/filter.h"
+#include "pcr/engine/glyph.h"
+#include "pcr/engine/pipeline.h"
+
+using namespace pcr;
+
+void bind_engine(py::module_& m) {
+    py::enum_<ExecutionMode>(m, "ExecutionMode")
+        .value("CPU", ExecutionMode::CPU).value("GPU", ExecutionMode::GPU)
+        .value("Auto", ExecutionMode::Auto).value("Hybrid", ExecutionMode::Hybrid).export_values();
+
+    py::enum_<CompareOp>(m, "CompareOp")
+        .value("Equal", CompareOp::Equal).value("NotEqual", CompareOp::NotEqual)
+        .value("Less", CompareOp::Less).value("LessEqual", CompareOp::LessEqual)
+        .value("Greater", CompareOp::Greater).value("GreaterEqual", CompareOp::GreaterEqual)
+        .value("InSet", CompareOp::InSet).value("NotInSet", CompareOp::NotInSet).export_values();
+
+    py::enum_<GlyphType>(m, "GlyphType")
+        .value("Point", GlyphType::Point).value("Line", GlyphType::Line)
+        .value("Gaussian", GlyphType::Gaussian).export_values();
+
+    py::class_<FilterPredicate>(m, "FilterPredicate")
+        .def(py::init<>())
+        .def_readwrite("channel_name", &FilterPredicate::channel_name)
+        .def_readwrite("op", &FilterPredicate::op)
+        .def_readwrite("value", &FilterPredicate::value)
+        .def_readwrite("value_set", &FilterPredicate::value_set);
+
+    py::class_<FilterSpec>(m, "FilterSpec")
+        .def(py::init<>())
+        .def_readwrite("predicates", &FilterSpec::predicates)
+        .def("add", &FilterSpec::add, py::arg("channel"), py::arg("op"), py::arg("value"),
+             py::return_value_policy::reference_internal)
+        .def("add_in_set", &FilterSpec::add_in_set, py::arg("channel"), py::arg("values"),
+             py::return_value_policy::reference_internal)
+        .def("empty", &FilterSpec::empty);
+
+    py::class_<GlyphSpec>(m, "GlyphSpec")
+        .def(py::init<>())
+        .def_readwrite("type", &GlyphSpec::type)
+        .def_readwrite("direction_channel", &GlyphSpec::direction_channel)
+        .def_readwrite("default_direction", &GlyphSpec::default_direction)
+        .def_readwrite("half_length_channel", &GlyphSpec::half_length_channel)
+        .def_readwrite("default_half_length", &GlyphSpec::default_half_length)
+        .def_readwrite("sigma_x_channel", &GlyphSpec::sigma_x_channel)
+        .def_readwrite("default_sigma_x", &GlyphSpec::default_sigma_x)
+        .def_readwrite("sigma_y_channel", &GlyphSpec::sigma_y_channel)
+        .def_readwrite("default_sigma_y", &GlyphSpec::default_sigma_y)
+        .def_readwrite("rotation_channel", &GlyphSpec::rotation_channel)
+        .def_readwrite("default_rotation", &GlyphSpec::default_rotation)
+        .def_readwrite("max_radius_cells", &GlyphSpec::max_radius_cells)
+        .def_readwrite("normalize_weights", &GlyphSpec::normalize_weights)
+        .def("__repr__", [](const GlyphSpec& g) {
+            static const char* names[] = {"Point", "Line", "Gaussian"};
+            return std::string("GlyphSpec(type=") + names[static_cast<int>(g.type)] + ")";
+        });
+
+    py::class_<ReductionSpec>(m, "ReductionSpec")
+        .def(py::init<>())
+        .def_readwrite("value_channel", &ReductionSpec::value_channel)
+        .def_readwrite("type", &ReductionSpec::type)
+        .def_readwrite("weight_channel", &ReductionSpec::weight_channel)
+        .def_readwrite("timestamp_channel", &ReductionSpec::timestamp_channel)
+        .def_readwrite("percentile", &ReductionSpec::percentile)
+        .def_readwrite("output_band_name", &ReductionSpec::output_band_name)
+        .def_readwrite("glyph", &ReductionSpec::glyph);
+
+    py::class_<PipelineConfig>(m, "PipelineConfig")
+        .def(py::init<>())
+        .def_readwrite("grid", &PipelineConfig::grid)
+        .def_readwrite("reductions", &PipelineConfig::reductions)
+        .def_readwrite("filter", &PipelineConfig::filter)
+        .def_readwrite("target_crs", &PipelineConfig::target_crs)
+        .def_readwrite("auto_reproject", &PipelineConfig::auto_reproject)
+        .def_readwrite("exec_mode", &PipelineConfig::exec_mode)
+        .def_readwrite("gpu_memory_budget", &PipelineConfig::gpu_memory_budget)
+        .def_readwrite("host_cache_budget", &PipelineConfig::host_cache_budget)
+        .def_readwrite("chunk_size", &PipelineConfig::chunk_size)
+        .def_readwrite("cpu_threads", &PipelineConfig::cpu_threads)
+        .def_readwrite("gpu_fallback_to_cpu", &PipelineConfig::gpu_fallback_to_cpu)
+        .def_readwrite("hybrid_cpu_threads", &PipelineConfig::hybrid_cpu_threads)
+        .def_readwrite("state_dir", &PipelineConfig::state_dir)
+        .def_readwrite("resume", &PipelineConfig::resume)
+        .def_readwrite("output_path", &PipelineConfig::output_path)
+        .def_readwrite("write_cog", &PipelineConfig::write_cog)
+        // fields the reference keeps C++-only, plus this build's extensions
+        .def_readwrite("gpu_pool_size_bytes", &PipelineConfig::gpu_pool_size_bytes)
+        .def_readwrite("cuda_device_id", &PipelineConfig::cuda_device_id)
+        .def_readwrite("use_cuda_streams", &PipelineConfig::use_cuda_streams)
+        .def_readwrite("gpu_require_strict", &PipelineConfig::gpu_require_strict)
+        .def_readwrite("result_location", &PipelineConfig::result_location)
+        .def_readwrite("shard_row_begin", &PipelineConfig::shard_row_begin)
+        .def_readwrite("shard_row_end", &PipelineConfig::shard_row_end)
+        .def_readwrite("scatter_path", &PipelineConfig::scatter_path);
+
+    py::class_<ProgressInfo>(m, "ProgressInfo")
+        .def(py::init<>())
+        .def_readwrite("collections_processed", &ProgressInfo::collections_processed)
+        .def_readwrite("collections_total", &ProgressInfo::collections_total)
+        .def_readwrite("points_processed", &ProgressInfo::points_processed)
+        .def_readwrite("tiles_active", &ProgressInfo::tiles_active)
+        .def_readwrite("elapsed_seconds", &ProgressInfo::elapsed_seconds)
+        .def("__repr__", [](const ProgressInfo& p) {
+            return "ProgressInfo(points=" + std::to_string(p.points_processed) + ", tiles=" +
+                   std::to_string(p.tiles_active) + ", elapsed=" + std::to_string(p.elapsed_seconds) + "s)";
+        });
+
+    py::class_<Pipeline>(m, "Pipeline")
+        .def_static("create", &Pipeline::create)      // None on failure; reason: pcr.pipeline_create_error()
+        .def("validate", [](const Pipeline& p) { raise_if_error(p.validate()); })
+        .def("ingest", [](Pipeline& p, const PointCloud& c) { raise_if_error(p.ingest(c)); })
+        .def("finalize", [](Pipeline& p) { raise_if_error(p.finalize()); })
+        .def("run", [](Pipeline& p, const std::vector<const PointCloud*>& cs) { raise_if_error(p.run(cs)); })
+        .def("set_progress_callback", &Pipeline::set_progress_callback)
+        .def("result", &Pipeline::result, py::return_value_policy::reference_internal)
+        .def("stats", &Pipeline::stats)
+        // extensions for row-block sharded (multi-GPU) runs
+        .def("halo_rows", &Pipeline::halo_rows)
+        .def("state_row_begin", &Pipeline::state_row_begin)
+        .def("state_row_count", &Pipeline::state_row_count)
+        .def("state_planes", [](const Pipeline& p) {
+            py::list out;
+            for (const auto& v : p.state_planes())
+                out.append(py::make_tuple(reinterpret_cast<uintptr_t>(v.device_ptr), v.plane_kind, v.group));
+            return out;
+        })
+        .def("tile_touched_ptr", [](const Pipeline& p) {
+            int tx = 0, ty = 0;
+            void* d = p.tile_touched_device(&tx, &ty);
+            return py::make_tuple(reinterpret_cast<uintptr_t>(d), tx, ty);
+        })
+        .def("synchronize", [](Pipeline& p) { raise_if_error(p.synchronize()); })
+        .def("profile_enable", &Pipeline::profile_enable)
+        .def("profile_read", [](Pipeline& p, bool reset) {
+            py::dict d;
+            for (const auto& k : p.profile_read(reset))
+                d[py::str(k.name)] = py::make_tuple(k.launches, k.total_ms);
+            return d;
+        }, py::arg("reset") = true)
+        .def("last_scatter", [](const Pipeline& p) {
+            auto s = p.last_scatter();
+            py::dict d;
+            d["path"] = s.path == 1 ? "binned" : "direct";
+            d["lds_tile"] = py::make_tuple(s.lds_tile_w, s.lds_tile_h);
+            d["lds_apron"] = s.lds_apron;
+            d["num_bins"] = s.num_bins;
+            d["points_in"] = s.points_in;
+            d["points_valid"] = s.points_valid;
+            return d;
+        });
+
+    m.def("pipeline_create_error", &pipeline_create_error,
+          "Why the last Pipeline.create() on this thread returned None");
+    m.def("device_count", &cuda_device_count);
+    m.def("device_name", &cuda_device_name, py::arg("device_id") = 0);
+}

@@ -40,6 +40,10 @@ class Glyph(C.Structure):
                 ("d_sigma_x", C.c_void_p), ("d_sigma_y", C.c_void_p), ("d_rotation", C.c_void_p)]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_double)]
+
+
 class ScatterStats(C.Structure):
     _fields_ = [("points_in", C.c_uint64), ("points_valid", C.c_uint64), ("path", C.c_int32),
                 ("lds_tile_w", C.c_int32), ("lds_tile_h", C.c_int32), ("lds_apron", C.c_int32),
@@ -88,6 +92,8 @@ SYMBOLS = {
     "pcr_hip_engine_set_path": [_VP, C.c_int],
     "pcr_hip_engine_stats": [_VP, C.POINTER(ScatterStats)],
     "pcr_hip_engine_tile_touched": [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "pcr_hip_engine_profile_enable": [_VP, C.c_int],
+    "pcr_hip_engine_profile_read": [_VP, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int), C.c_int],
     "pcr_hip_scatter_point": [_VP, _U32, C.POINTER(Planes), _VP, _VP, _VP, _U64],
     "pcr_hip_scatter_glyph": [_VP, C.POINTER(Glyph), _U32, C.POINTER(Planes), _VP, _VP, _VP, _U64],
 }

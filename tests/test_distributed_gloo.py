@@ -1,0 +1,110 @@
+"""The N > 1 path on CPU: row-block partition + neighbour halo reduce over gloo (world_size 2 and 3).
+
+Each rank's state planes are produced by the CPU oracle restricted to the rank's row window
+(own rows +- halo), exactly what a sharded device engine holds; after exchange_halos the owned
+rows must equal the unsharded oracle result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+    import pcr_oracle_py as O
+    from pcr.distributed import exchange_halos, row_block, allreduce_touched, PLANE_SUM, PLANE_WGT, PLANE_MAX
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, H, halo = 48, 60, 6
+        og = O.make_grid((0, 0, W, H))
+        rng = np.random.default_rng(3)
+        n = 4000
+        x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
+        v = rng.uniform(0, 1, n).astype(np.float32)
+        gl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=2.0, max_radius=float(halo))
+        blocks = [row_block(r, world, H) for r in range(world)]
+        r0, r1 = blocks[rank]
+        s0, s1 = max(0, r0 - halo), min(H, r1 + halo)
+        # what this rank's engine would hold: only points whose centre row is in [r0, r1),
+        # footprints accumulated over rows [s0, s1)
+        rows = np.floor((y - og.max_y) / og.cell_size_y).clip(0, H - 1).astype(int)
+        mine = (rows >= r0) & (rows < r1)
+        num = O.run(og, O.SUM, x[mine], y[mine], v[mine], glyph=gl) if mine.any() else np.zeros((H, W), np.float32)
+        den = O.run(og, O.COUNT, x[mine], y[mine], v[mine], glyph=gl) if mine.any() else np.full((H, W), np.nan, np.float32)
+        num = np.nan_to_num(num)[s0:s1].copy()
+        den = np.nan_to_num(den)[s0:s1].copy()
+        mx = np.full((s1 - s0, W), -3.4e38, np.float32)
+        mx[(r0 - s0):(r1 - s0)] = rank            # a max plane: owned rows carry the rank id
+        if s0 < r0:
+            mx[: r0 - s0] = 100 + rank            # apron rows destined for the upper neighbour
+        planes = [(torch.from_numpy(num), PLANE_SUM), (torch.from_numpy(den), PLANE_WGT),
+                  (torch.from_numpy(mx), PLANE_MAX)]
+        exchange_halos(planes, (r0, r1), s0, halo, rank, world, blocks=blocks)
+        touched = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
+        allreduce_touched(touched)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), num=num[(r0 - s0):(r1 - s0)], den=den[(r0 - s0):(r1 - s0)],
+                 mx=mx[(r0 - s0):(r1 - s0)], own=np.array([r0, r1]), touched=touched.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_matches_unsharded(world, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcr_oracle_py as O
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    W, H, halo = 48, 60, 6
+    og = O.make_grid((0, 0, W, H))
+    rng = np.random.default_rng(3)
+    n = 4000
+    x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    gl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=2.0, max_radius=float(halo))
+    num = np.nan_to_num(O.run(og, O.SUM, x, y, v, glyph=gl))
+    den = np.nan_to_num(O.run(og, O.COUNT, x, y, v, glyph=gl))
+    rows_seen = 0
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        r0, r1 = d["own"]
+        rows_seen += r1 - r0
+        np.testing.assert_allclose(d["num"], num[r0:r1], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(d["den"], den[r0:r1], rtol=1e-5, atol=1e-6)
+        # max plane: my last `halo` rows received the lower neighbour's apron (100 + its rank)
+        if r < world - 1:
+            assert (d["mx"][-halo:] == 100 + r + 1).all() and (d["mx"][:-halo] == r).all()
+        else:
+            assert (d["mx"] == r).all()
+        assert d["touched"].tolist() == [1, 0]
+    assert rows_seen == H
+
+
+def test_row_block_partition():
+    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+    from pcr.distributed import row_block
+    assert [row_block(r, 8, 16384) for r in range(8)] == [(2048 * r, 2048 * (r + 1)) for r in range(8)]
+    blocks = [row_block(r, 3, 100) for r in range(3)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == 100
+    assert all(blocks[i][1] == blocks[i + 1][0] for i in range(2))
+    # tile-aligned blocks (exchange-free for tile-clipped glyphs): 10 tiles of 4096 over 4 ranks
+    blocks = [row_block(r, 4, 40000, align=4096) for r in range(4)]
+    assert all(b0 % 4096 == 0 for b0, _ in blocks) and blocks[-1][1] == 40000
+    assert row_block(0, 1, 77) == (0, 77)
