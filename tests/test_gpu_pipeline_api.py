@@ -134,7 +134,7 @@ def test_error_messages_match_reference():
     pipe.ingest(cloud_from([1.0], [1.0], {"value": [1]}))
     with pytest.raises(RuntimeError, match="GeoTIFF writing is not part of this build"):
         pipe.finalize()
-    assert pipe.result().band_array(0)[8, 1] == 1.0
+    assert pipe.result().band_array(0)[9, 1] == 1.0
 
 
 @pytest.mark.parametrize("path", [1, 0])
