@@ -23,7 +23,8 @@ import cases  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 RT = {"Sum": 0, "Max": 1, "Min": 2, "Average": 3, "WeightedAverage": 4, "Count": 5}
-PATHS = [1, 0]   # direct, auto (binned where applicable)
+PATHS = [1, 0]        # glyphs: direct, auto
+POINT_PATHS = [1, 2, 0]  # Point glyph: direct, forced binned LDS tiles, auto
 
 
 def mask_for(A, rtype):
@@ -55,7 +56,7 @@ def A():
     return mod
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 def test_reference_pipeline_known_answers(A, known_answers, denan, path):
     for case in known_answers["pipeline"]:
         og = grid_from_json(O, case["grid"])
@@ -76,7 +77,7 @@ def uniform_cloud(n, g, seed, margin=2.0, value="uniform"):
     return x, y, v
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 @pytest.mark.parametrize("rname", ["Sum", "Max", "Min", "Average", "WeightedAverage", "Count"])
 @pytest.mark.parametrize("gridspec", [
     dict(bounds=(0, 0, 256, 256), tile=(4096, 4096)),          # one tile
@@ -109,7 +110,7 @@ def test_point_ops_random(A, rname, gridspec, path):
         assert_band_close(got, want, rtol=2e-5, atol=2e-3, what=f"{rname} vs fp32 oracle")
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 def test_fused_planes_one_pass(A, path):
     """Sum + Count + Average + Max + Min from ONE scatter over the points (plane_mask = 15)."""
     og = O.make_grid((0, 0, 200, 120), tile=(4096, 4096))
@@ -128,7 +129,7 @@ def test_fused_planes_one_pass(A, path):
         run.close()
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 def test_bounds_edges_q1(A, path):
     # inclusive bounds + clamp (Q1): corners and edges land in the outermost cells
     og = O.make_grid((0, 0, 4, 4))
@@ -142,7 +143,7 @@ def test_bounds_edges_q1(A, path):
     assert got[3, 0] == 1 and got[0, 3] == 1 and got[3, 3] == 1 and got[0, 2] == 1 and got[0, 0] == 1
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 def test_special_values_min_max_sum(A, path):
     og = O.make_grid((0, 0, 4, 1))
     x = np.array([0.5, 0.5, 1.5, 1.5, 2.5, 2.5, 3.5])
@@ -154,7 +155,7 @@ def test_special_values_min_max_sum(A, path):
         assert_band_close(got, want, what=rname)
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 def test_empty_and_all_out_of_bounds(A, path):
     og = O.make_grid((0, 0, 16, 16), tile=(8, 8))
     e = np.zeros(0)
@@ -165,7 +166,7 @@ def test_empty_and_all_out_of_bounds(A, path):
     assert np.isnan(got).all() and st.points_valid == 0
 
 
-@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("path", POINT_PATHS)
 def test_state_survives_finalize_and_multi_ingest(A, path):
     # quirk Q9: finalize does not reset; a second ingest accumulates on top
     og = O.make_grid((0, 0, 64, 64))
