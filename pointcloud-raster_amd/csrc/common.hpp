@@ -80,10 +80,22 @@ int validate_grid(const pcr_hip_grid* g);
 // ---- routing: GridConfig::world_to_cell (src/core/grid_config.cpp:24-43) ------
 // Inclusive bounds (BBox::contains, src/core/types.cpp:41-43), floor of a TRUE f64
 // division, clamp.  NaN coordinates fail the bounds test, as on the CPU.
+// floor(fl(a / cs)) without paying an IEEE f64 division per point: a * (1/cs) is within
+// 3.4e-16*|q| of the correctly rounded quotient, so the two can only floor differently when the
+// product sits within a few ulps of an integer -- only those lanes take the true division.
+__device__ __forceinline__ double floor_quotient(double a, double cs, double inv_cs) {
+    double q = a * inv_cs;
+    double fl = floor(q);
+    double frac = q - fl;
+    double eps = fmax(fabs(q), 1.0) * 8.9e-16;
+    if (!(frac >= eps && frac <= 1.0 - eps)) fl = floor(a / cs);     // also catches NaN/inf
+    return fl;
+}
+
 __device__ __forceinline__ bool world_to_cell(const GridDev& g, double wx, double wy, int& col, int& row) {
     if (!(wx >= g.min_x && wx <= g.max_x && wy >= g.min_y && wy <= g.max_y)) return false;
-    int c = (int)floor((wx - g.min_x) / g.csx);
-    int r = (int)floor((wy - g.max_y) / g.csy);
+    int c = (int)floor_quotient(wx - g.min_x, g.csx, g.inv_csx);
+    int r = (int)floor_quotient(wy - g.max_y, g.csy, g.inv_csy);
     c = max(0, min(c, g.W - 1));
     r = max(0, min(r, g.H - 1));
     col = c;

@@ -38,12 +38,13 @@ struct Record {                         // 8 bytes
     float value;
 };
 
-// LDS tile shape by number of planes: 128 KB of tile per workgroup at most.
+// LDS tile shape: 128 columns x as many rows (multiple of 8, <= 128) as fit ~150 KB of the CU's
+// 160 KB LDS at the per-cell footprint of the requested planes (sum 8 B, weight/max/min 4 B each).
 inline BinGeom bin_geom(const GridDev& g, uint32_t mask) {
-    int planes = __builtin_popcount(mask);
+    int cell_bytes = ((mask & 1) ? 8 : 0) + ((mask & 2) ? 4 : 0) + ((mask & 4) ? 4 : 0) + ((mask & 8) ? 4 : 0);
     BinGeom b;
     b.tile_w = 128;
-    b.tile_h = planes <= 2 ? 128 : 64;
+    b.tile_h = std::min(128, (150 * 1024 / (std::max(cell_bytes, 4) * 128)) & ~7);
     b.bins_x = (g.W + b.tile_w - 1) / b.tile_w;
     b.bins_y = (g.st_rows + b.tile_h - 1) / b.tile_h;
     b.nbins = b.bins_x * b.bins_y;
@@ -73,8 +74,8 @@ __device__ __forceinline__ Routed route(const GridDev& g, const BinGeom& b, doub
 // ---- pass A: histogram ----------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads)
 k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
-            uint64_t n, unsigned* __restrict__ bin_count, uint32_t* __restrict__ touched,
-            unsigned long long* __restrict__ counters) {
+            uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
+            uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < b.nbins; i += kThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
@@ -83,14 +84,46 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     const bool one_tile = g.tiles_x * g.tiles_y == 1;
     const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
     unsigned my_valid = 0;
-    for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
-        uint64_t i = base + k;
-        if (i >= n) break;
-        Routed r = route(g, b, x[i], y[i]);
+    // The routing is done once: pass B reads the 4-byte key written here instead of x, y (16 B).
+    auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
+        Routed r = route(g, b, wx, wy);
         if (r.valid) {
             atomicAdd(&lds_hist[r.bin], 1u);
             ++my_valid;
             if (!one_tile) touch_tile(g, touched, r.row, r.col);
+            return ((unsigned)r.bin << kLcellBits) | r.lcell;
+        }
+        return 0xFFFFFFFFu;
+    };
+    const bool full = base + (uint64_t)b.chunk <= n &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(keys) & 7) == 0;
+    if (full) {
+        // 16-byte loads (two points per lane), four of them in flight per array before any math
+        const double2* x2 = reinterpret_cast<const double2*>(x + base);
+        const double2* y2 = reinterpret_cast<const double2*>(y + base);
+        uint2* k2 = reinterpret_cast<uint2*>(keys + base);
+        const int pairs = b.chunk >> 1;
+        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kThreads) {
+            double2 xs[4], ys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xs[u] = x2[p0 + u * kThreads];
+                ys[u] = y2[p0 + u * kThreads];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint64_t i = base + 2ull * (p0 + u * kThreads);
+                unsigned ka = handle(i, xs[u].x, ys[u].x);
+                unsigned kb = handle(i + 1, xs[u].y, ys[u].y);
+                k2[p0 + u * kThreads] = make_uint2(ka, kb);
+            }
+        }
+    } else {
+        for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
+            uint64_t i = base + k;
+            if (i >= n) break;
+            keys[i] = handle(i, x[i], y[i]);
         }
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
@@ -159,11 +192,12 @@ k_bin_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restri
 }
 
 // ---- pass B: scatter records, staged through LDS so that every bin's run is written contiguously
-template <int PER_THREAD>
+// VEC: every block of the launch is a full chunk and keys/v are 16-byte aligned (16-byte loads,
+// four consecutive points per lane); the ragged last chunk is a second, scalar launch.
+template <int PER_THREAD, bool VEC>
 __global__ void __launch_bounds__(kThreads)
-k_bin_scatter(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
-              const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor,
-              Record* __restrict__ records) {
+k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, const float* __restrict__ v,
+              uint64_t n, unsigned* __restrict__ cursor, Record* __restrict__ records) {
     extern __shared__ unsigned char lds_raw[];
     // layout: stage[chunk] (8 B each) | hist[nbins] | loff[nbins] | gbase[nbins]
     uint2* stage = reinterpret_cast<uint2*>(lds_raw);
@@ -175,24 +209,38 @@ k_bin_scatter(GridDev g, BinGeom b, const double* __restrict__ x, const double* 
     for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
     __syncthreads();
 
-    const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
+    const uint64_t base = (uint64_t)(blockIdx.x + first_block) * b.chunk;
     unsigned key[PER_THREAD], rank[PER_THREAD];
     float val[PER_THREAD];
+    if (VEC) {
+        // 16-byte loads: four consecutive points per lane per load
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
+        const float4* v4 = reinterpret_cast<const float4*>(v + base);
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-        uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
-        key[k] = 0xFFFFFFFFu;
-        rank[k] = 0;
-        val[k] = 0.0f;
-        if (i < n) {
-            Routed r = route(g, b, x[i], y[i]);
-            if (r.valid) {
-                key[k] = ((unsigned)r.bin << kLcellBits) | r.lcell;
-                rank[k] = atomicAdd(&hist[r.bin], 1u);         // rank of the point inside (block, bin)
+        for (int q = 0; q < PER_THREAD / 4; ++q) {
+            uint4 kk = k4[q * kThreads + threadIdx.x];
+            float4 vv = v ? v4[q * kThreads + threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+            key[4 * q + 0] = kk.x; key[4 * q + 1] = kk.y; key[4 * q + 2] = kk.z; key[4 * q + 3] = kk.w;
+            val[4 * q + 0] = vv.x; val[4 * q + 1] = vv.y; val[4 * q + 2] = vv.z; val[4 * q + 3] = vv.w;
+        }
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) rank[k] = 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) {
+            uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+            key[k] = 0xFFFFFFFFu;
+            rank[k] = 0;
+            val[k] = 0.0f;
+            if (i < n) {
+                key[k] = keys[i];
                 if (v) val[k] = v[i];
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k)
+        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);   // rank inside (block, bin)
     __syncthreads();
 
     // block-wide exclusive scan of hist -> loff; reserve global ranges per non-empty bin
@@ -243,37 +291,64 @@ k_bin_scatter(GridDev g, BinGeom b, const double* __restrict__ x, const double* 
 }
 
 // ---- pass C: fold a work item's records into an LDS tile, merge the tile into the state planes
+// ---- pass C: fold a work item's records into an LDS tile, merge the tile into the state planes
+//
+// LDS atomics on gfx950 (tools/ubench_lds_atomics*.hip, measured): ds_add_f32 costs ~194 cycles
+// per wave-instruction per CU whatever the addresses (lanes are serialized); ds_add_u32 / ds_max_i32
+// ~7, ds_add_u64 ~12, ds_add_f64 ~22.  So the LDS copy of a tile is NOT float32:
+//   sum    -> double, ds_add_f64  (also makes the tile sum exact to f32 precision)
+//   weight -> u32,    ds_add_u32  (a Point-glyph weight is 1; exact)
+//   max/min-> f32 bits, integer ds_max/ds_min (common.hpp)
+// and is rounded to f32 once, when it is merged into the f32 state planes.
+constexpr int kBytesSum = 8, kBytesWgt = 4, kBytesMax = 4, kBytesMin = 4;
+
+__host__ __device__ inline int tile_cell_bytes(unsigned mask) {
+    return ((mask & 1) ? kBytesSum : 0) + ((mask & 2) ? kBytesWgt : 0) + ((mask & 4) ? kBytesMax : 0) +
+           ((mask & 8) ? kBytesMin : 0);
+}
+
 template <unsigned MASK>
 __global__ void __launch_bounds__(kThreads)
 k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const Record* __restrict__ records,
              const Item* __restrict__ items, const unsigned* __restrict__ n_items) {
-    extern __shared__ float lds_tile[];
-    constexpr int kPlanes = ((MASK & 1) ? 1 : 0) + ((MASK & 2) ? 1 : 0) + ((MASK & 4) ? 1 : 0) + ((MASK & 8) ? 1 : 0);
+    extern __shared__ double lds_tile[];
     if (blockIdx.x >= *n_items) return;
     const Item it = items[blockIdx.x];
-    const int cells = b.tile_w * b.tile_h;
-    float* t_sum = lds_tile;
-    float* t_wgt = t_sum + ((MASK & 1) ? cells : 0);
-    float* t_max = t_wgt + ((MASK & 2) ? cells : 0);
+    const int cells = b.tile_w * b.tile_h;                     // multiple of 1024
+    double* t_sum = lds_tile;
+    unsigned* t_wgt = reinterpret_cast<unsigned*>(t_sum + ((MASK & 1) ? cells : 0));
+    float* t_max = reinterpret_cast<float*>(t_wgt + ((MASK & 2) ? cells : 0));
     float* t_min = t_max + ((MASK & 4) ? cells : 0);
-    (void)kPlanes;
 
+    // identity fill
     for (int i = threadIdx.x; i < cells; i += kThreads) {
-        if (MASK & 1) t_sum[i] = 0.0f;
-        if (MASK & 2) t_wgt[i] = 0.0f;
+        if (MASK & 1) t_sum[i] = 0.0;
+        if (MASK & 2) t_wgt[i] = 0u;
         if (MASK & 4) t_max[i] = -FLT_MAX;
         if (MASK & 8) t_min[i] = FLT_MAX;
     }
     __syncthreads();
 
+    // records: kUnroll independent 8-byte loads in flight per lane (64 KB per CU) ahead of the
+    // dependent LDS atomics
+    constexpr int kUnroll = 8;
     const uint2* rec = reinterpret_cast<const uint2*>(records) + it.first;
-    for (unsigned j = threadIdx.x; j < it.count; j += kThreads) {
-        uint2 r = rec[j];
-        float val = __uint_as_float(r.y);
-        if (MASK & 1) atomic_add_f32(&t_sum[r.x], val);
-        if (MASK & 2) atomic_add_f32(&t_wgt[r.x], 1.0f);
-        if (MASK & 4) atomic_max_f32(&t_max[r.x], val);
-        if (MASK & 8) atomic_min_f32(&t_min[r.x], val);
+    for (unsigned j0 = threadIdx.x; j0 < it.count; j0 += kUnroll * kThreads) {
+        uint2 r[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            unsigned j = j0 + u * kThreads;
+            r[u] = j < it.count ? rec[j] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (r[u].x == 0xFFFFFFFFu) continue;
+            float val = __uint_as_float(r[u].y);
+            if (MASK & 1) unsafeAtomicAdd(&t_sum[r[u].x], (double)val);
+            if (MASK & 2) atomicAdd(&t_wgt[r[u].x], 1u);
+            if (MASK & 4) atomic_max_f32(&t_max[r[u].x], val);
+            if (MASK & 8) atomic_min_f32(&t_min[r[u].x], val);
+        }
     }
     __syncthreads();
 
@@ -281,19 +356,56 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const Record* __restrict__ reco
     const int bx = it.bin % b.bins_x, by = it.bin / b.bins_x;
     const int c0 = bx * b.tile_w, r0 = by * b.tile_h;                 // r0 relative to the state window
     const int w = min(b.tile_w, g.W - c0), h = min(b.tile_h, g.st_rows - r0);
+    const bool vec = !it.shared && (g.W % 4 == 0) && (w % 4 == 0) &&
+                     ((((MASK & 1) ? reinterpret_cast<uintptr_t>(pl.sum) : 0) | ((MASK & 2) ? reinterpret_cast<uintptr_t>(pl.wgt) : 0) |
+                       ((MASK & 4) ? reinterpret_cast<uintptr_t>(pl.mx) : 0) | ((MASK & 8) ? reinterpret_cast<uintptr_t>(pl.mn) : 0)) & 15) == 0;
+    if (vec) {
+        // one lane = 4 consecutive cells of a row: wide LDS reads, float4 global RMW; the planes'
+        // loads of an iteration are independent and issued together
+        const int qrow = b.tile_w >> 2;
+        for (int i = threadIdx.x; i < qrow * h; i += kThreads) {
+            int ly = i / qrow, lx = (i - ly * qrow) << 2;
+            if (lx >= w) continue;
+            int64_t cell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
+            int li = ly * b.tile_w + lx;
+            float4 a1, a2, a4, a8, g1, g2, g4, g8;
+            bool n1 = false, n2 = false, n4 = false, n8 = false;
+            if (MASK & 1) {
+                double2 lo = *reinterpret_cast<const double2*>(t_sum + li), hi = *reinterpret_cast<const double2*>(t_sum + li + 2);
+                a1 = make_float4((float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y);
+                n1 = (lo.x != 0.0) | (lo.y != 0.0) | (hi.x != 0.0) | (hi.y != 0.0);
+            }
+            if (MASK & 2) {
+                uint4 c = *reinterpret_cast<const uint4*>(t_wgt + li);
+                a2 = make_float4((float)c.x, (float)c.y, (float)c.z, (float)c.w);
+                n2 = (c.x | c.y | c.z | c.w) != 0u;
+            }
+            if (MASK & 4) { a4 = *reinterpret_cast<const float4*>(t_max + li); n4 = (a4.x != -FLT_MAX) | (a4.y != -FLT_MAX) | (a4.z != -FLT_MAX) | (a4.w != -FLT_MAX); }
+            if (MASK & 8) { a8 = *reinterpret_cast<const float4*>(t_min + li); n8 = (a8.x != FLT_MAX) | (a8.y != FLT_MAX) | (a8.z != FLT_MAX) | (a8.w != FLT_MAX); }
+            if ((MASK & 1) && n1) g1 = *reinterpret_cast<const float4*>(pl.sum + cell);
+            if ((MASK & 2) && n2) g2 = *reinterpret_cast<const float4*>(pl.wgt + cell);
+            if ((MASK & 4) && n4) g4 = *reinterpret_cast<const float4*>(pl.mx + cell);
+            if ((MASK & 8) && n8) g8 = *reinterpret_cast<const float4*>(pl.mn + cell);
+            if ((MASK & 1) && n1) { g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w; *reinterpret_cast<float4*>(pl.sum + cell) = g1; }
+            if ((MASK & 2) && n2) { g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w; *reinterpret_cast<float4*>(pl.wgt + cell) = g2; }
+            if ((MASK & 4) && n4) { g4.x = fmaxf(g4.x, a4.x); g4.y = fmaxf(g4.y, a4.y); g4.z = fmaxf(g4.z, a4.z); g4.w = fmaxf(g4.w, a4.w); *reinterpret_cast<float4*>(pl.mx + cell) = g4; }
+            if ((MASK & 8) && n8) { g8.x = fminf(g8.x, a8.x); g8.y = fminf(g8.y, a8.y); g8.z = fminf(g8.z, a8.z); g8.w = fminf(g8.w, a8.w); *reinterpret_cast<float4*>(pl.mn + cell) = g8; }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < b.tile_w * h; i += kThreads) {
         int ly = i / b.tile_w, lx = i - ly * b.tile_w;
         if (lx >= w) continue;
         int64_t cell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
         int li = ly * b.tile_w + lx;
         if (!it.shared) {
-            if (MASK & 1) { float a = t_sum[li]; if (a != 0.0f) pl.sum[cell] += a; }
-            if (MASK & 2) { float a = t_wgt[li]; if (a != 0.0f) pl.wgt[cell] += a; }
+            if (MASK & 1) { double a = t_sum[li]; if (a != 0.0) pl.sum[cell] += (float)a; }
+            if (MASK & 2) { unsigned a = t_wgt[li]; if (a) pl.wgt[cell] += (float)a; }
             if (MASK & 4) { float a = t_max[li]; if (a != -FLT_MAX) pl.mx[cell] = fmaxf(pl.mx[cell], a); }
             if (MASK & 8) { float a = t_min[li]; if (a != FLT_MAX) pl.mn[cell] = fminf(pl.mn[cell], a); }
         } else {
-            if (MASK & 1) { float a = t_sum[li]; if (a != 0.0f) atomic_add_f32(pl.sum + cell, a); }
-            if (MASK & 2) { float a = t_wgt[li]; if (a != 0.0f) atomic_add_f32(pl.wgt + cell, a); }
+            if (MASK & 1) { double a = t_sum[li]; if (a != 0.0) atomic_add_f32(pl.sum + cell, (float)a); }
+            if (MASK & 2) { unsigned a = t_wgt[li]; if (a) atomic_add_f32(pl.wgt + cell, (float)a); }
             if (MASK & 4) { float a = t_max[li]; if (a != -FLT_MAX) atomic_max_f32(pl.mx + cell, a); }
             if (MASK & 8) { float a = t_min[li]; if (a != FLT_MAX) atomic_min_f32(pl.mn + cell, a); }
         }
@@ -303,8 +415,7 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const Record* __restrict__ reco
 template <unsigned MASK>
 void launch_accum(pcr_hip_engine* e, const BinGeom& b, const PlanesDev& pl, const Record* rec,
                   const Item* items, const unsigned* n_items, int max_items) {
-    int planes = __builtin_popcount(MASK);
-    size_t lds = (size_t)b.tile_w * b.tile_h * sizeof(float) * planes;
+    size_t lds = (size_t)b.tile_w * b.tile_h * tile_cell_bytes(MASK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_accum<MASK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(max_items), dim3(kThreads), lds, e->stream, e->gd, b, pl,
@@ -341,6 +452,7 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     const size_t o_nitems = off; off += 256;
     const size_t o_items = off;  off += align256((size_t)max_items * sizeof(Item));
     const size_t o_rec = off;    off += align256((size_t)n * sizeof(Record));
+    const size_t o_keys = off;   off += align256((size_t)n * sizeof(unsigned));
     int rc = ensure_scratch(e, off);
     if (rc) return rc;
     char* s = e->d_scratch;
@@ -350,12 +462,13 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     unsigned* d_nitems = reinterpret_cast<unsigned*>(s + o_nitems);
     Item* d_items = reinterpret_cast<Item*>(s + o_items);
     Record* d_rec = reinterpret_cast<Record*>(s + o_rec);
+    unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
 
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
         hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream,
-                           e->gd, b, x, y, n, d_count, e->d_touched, e->d_counters);
+                           e->gd, b, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
@@ -365,16 +478,21 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     {
         ScopedKernelTimer t(e, "k_bin_scatter");
         size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 3;
+        const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;        // d_keys is 256-byte aligned
+        const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
+        auto launch = [&](auto kernel, int nblocks, int first) {
+            if (nblocks <= 0) return;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, b, first, d_keys, v, n,
+                               d_cursor, d_rec);
+        };
         if (b.chunk == 16384) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter<16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_bin_scatter<16>), dim3(blocks), dim3(kThreads), lds, e->stream, e->gd, b,
-                               x, y, v, n, d_cursor, d_rec);
+            launch(&k_bin_scatter<16, true>, full_blocks, 0);
+            launch(&k_bin_scatter<16, false>, blocks - full_blocks, full_blocks);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter<8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_bin_scatter<8>), dim3(blocks), dim3(kThreads), lds, e->stream, e->gd, b,
-                               x, y, v, n, d_cursor, d_rec);
+            launch(&k_bin_scatter<8, true>, full_blocks, 0);
+            launch(&k_bin_scatter<8, false>, blocks - full_blocks, full_blocks);
         }
     }
     {
