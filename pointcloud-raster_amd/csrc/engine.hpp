@@ -52,6 +52,31 @@ struct ScopedKernelTimer {
     }
 };
 
+// ---- binning (counting sort of points by LDS tile), scatter_binned.hip ------------------------
+struct BinGeom {
+    int tile_w, tile_h;                 // interior of an LDS tile, cells (a bin owns these cells)
+    int bins_x, bins_y, nbins;
+    int chunk;                          // points per workgroup in the count / scatter passes
+};
+struct BinItem {                        // one workgroup's share of a bin's records
+    unsigned bin, first, count, shared; // shared != 0: the bin was split, merge with atomics
+};
+struct BinBuffers {                     // device pointers into the engine's scratch arena
+    const uint2* records;               // grouped by bin; .x = local cell, .y = value bits or point index
+    const BinItem* items;
+    const unsigned* n_items;
+    int max_items;
+};
+constexpr int kMaxBins = 4096;
+constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
+
+// Passes A (histogram + routing keys), scan, B (LDS-staged scatter).  index_records: record.y is
+// the point's index (glyph paths re-read x, y, v, channels by index) instead of its value.
+// extra_scratch bytes are reserved after the binning buffers and returned through *extra.
+int bin_points(pcr_hip_engine* e, const BinGeom& b, const double* x, const double* y, const float* v,
+               uint64_t n, bool index_records, unsigned item_records, BinBuffers* out,
+               size_t extra_scratch = 0, void** extra = nullptr);
+
 // direct path (global atomics), scatter_direct.hip
 int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n);

@@ -76,6 +76,23 @@ __device__ __forceinline__ GaussParams gauss_params(const GridDev& g, const Glyp
     return q;
 }
 
+// Lane `src`'s parameters, made wave-uniform (v_readlane into SGPRs; src must be uniform).
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+__device__ __forceinline__ GaussParams lane_bcast(const GaussParams& q, int src) {
+    GaussParams u;
+    u.val = lane_bcast(q.val, src); u.sub_cx = lane_bcast(q.sub_cx, src); u.sub_cy = lane_bcast(q.sub_cy, src);
+    u.sx = lane_bcast(q.sx, src); u.sy = lane_bcast(q.sy, src);
+    u.cos_r = lane_bcast(q.cos_r, src); u.sin_r = lane_bcast(q.sin_r, src);
+    u.icx = lane_bcast(q.icx, src); u.icy = lane_bcast(q.icy, src); u.r = lane_bcast(q.r, src);
+    u.cx0 = lane_bcast(q.cx0, src); u.cx1 = lane_bcast(q.cx1, src);
+    u.cy0 = lane_bcast(q.cy0, src); u.cy1 = lane_bcast(q.cy1, src);
+    return u;
+}
+
 // Weight of offset (dx, dy): glyph_kernels.cu:157-166.
 __device__ __forceinline__ float gauss_weight(const GaussParams& q, int dx, int dy) {
     float rdx = (float)dx - q.sub_cx;

@@ -1,17 +1,18 @@
-// scatter_binned.hip -- the binned LDS-tile scatter path (Point glyph).
+// scatter_binned.hip -- the binned LDS-tile scatter path: binning passes + Point-glyph tiles.
 //
 // Random per-point atomics into a 134 MB state run at the memory-side atomic rate
 // (~9 G atomics/s measured, scatter_direct.hip).  Here the grid is cut into LDS tiles
-// ("bins", e.g. 128x128 cells); points are counting-sorted by bin (one histogram pass, one
-// scatter pass with LDS-staged, coalesced record writes), then ONE workgroup per bin folds its
-// records into an LDS copy of the tile with LDS atomics and merges the tile into the HBM state
-// planes with plain coalesced read-modify-writes (a bin is owned by exactly one workgroup per
-// launch, so no global atomics at all unless a hot bin had to be split).
+// ("bins"); points are counting-sorted by bin (one histogram pass that also writes a 4-byte
+// routing key per point, one scatter pass with LDS-staged, coalesced record writes), then ONE
+// workgroup per bin folds its records into an LDS copy of the tile with LDS atomics and merges
+// the tile into the HBM state planes with plain coalesced read-modify-writes (a bin is owned by
+// exactly one workgroup per launch, so no global atomics unless a hot bin had to be split).
 //
-//   k_bin_count    x,y            -> bin histogram (LDS) -> global bin counts, touched tiles
+//   k_bin_count    x,y            -> routing keys, bin histogram (LDS) -> global bin counts, touched tiles
 //   k_bin_scan     counts         -> bin starts, cursors, work items (heavy bins are split)
-//   k_bin_scatter  x,y,v          -> records {local cell, value} grouped by bin
-//   k_tile_accum   records, state -> state   (LDS atomics + merge pass)
+//   k_bin_scatter  keys,v         -> records {local cell, value | point index} grouped by bin
+//   k_tile_accum   records, state -> state   (LDS atomics + merge pass)       [Point glyph]
+//   (glyph tiles: scatter_binned_glyph.hip)
 //
 // Replaces the reference's sort-by-(tile,cell) + per-tile accumulate
 // (src/engine/tile_router_kernels.cu:63-293, src/engine/accumulator_kernels.cu:31-133).
@@ -21,36 +22,9 @@ using namespace pcrhip;
 
 namespace {
 
-constexpr int kThreads = 1024;          // all four kernels' heavy phases use full-CU workgroups
-constexpr int kMaxBins = 4096;
-constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
+constexpr int kThreads = 1024;          // full-CU workgroups
 constexpr unsigned kLcellMask = (1u << kLcellBits) - 1;
-constexpr int kItemRecords = 1 << 17;   // a bin with more records than this is split into several work items
-
-struct BinGeom {
-    int tile_w, tile_h;                 // LDS tile, cells
-    int bins_x, bins_y, nbins;
-    int chunk;                          // points per workgroup in the count / scatter passes
-};
-
-struct Record {                         // 8 bytes
-    unsigned lcell;
-    float value;
-};
-
-// LDS tile shape: 128 columns x as many rows (multiple of 8, <= 128) as fit ~150 KB of the CU's
-// 160 KB LDS at the per-cell footprint of the requested planes (sum 8 B, weight/max/min 4 B each).
-inline BinGeom bin_geom(const GridDev& g, uint32_t mask) {
-    int cell_bytes = ((mask & 1) ? 8 : 0) + ((mask & 2) ? 4 : 0) + ((mask & 4) ? 4 : 0) + ((mask & 8) ? 4 : 0);
-    BinGeom b;
-    b.tile_w = 128;
-    b.tile_h = std::min(128, (150 * 1024 / (std::max(cell_bytes, 4) * 128)) & ~7);
-    b.bins_x = (g.W + b.tile_w - 1) / b.tile_w;
-    b.bins_y = (g.st_rows + b.tile_h - 1) / b.tile_h;
-    b.nbins = b.bins_x * b.bins_y;
-    b.chunk = b.nbins <= 2048 ? 16384 : 8192;
-    return b;
-}
+constexpr unsigned kPointItemRecords = 1u << 17;   // a bin with more records is split into several work items
 
 // ---- shared per-point routing --------------------------------------------------------------
 struct Routed {
@@ -71,7 +45,7 @@ __device__ __forceinline__ Routed route(const GridDev& g, const BinGeom& b, doub
     return r;
 }
 
-// ---- pass A: histogram ----------------------------------------------------------------------
+// ---- pass A: routing keys + histogram -------------------------------------------------------
 __global__ void __launch_bounds__(kThreads)
 k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
             uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
@@ -85,7 +59,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
     unsigned my_valid = 0;
     // The routing is done once: pass B reads the 4-byte key written here instead of x, y (16 B).
-    auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
+    auto handle = [&](double wx, double wy) -> unsigned {
         Routed r = route(g, b, wx, wy);
         if (r.valid) {
             atomicAdd(&lds_hist[r.bin], 1u);
@@ -96,8 +70,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         return 0xFFFFFFFFu;
     };
     const bool full = base + (uint64_t)b.chunk <= n &&
-                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
-                      (reinterpret_cast<uintptr_t>(keys) & 7) == 0;
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (full) {
         // 16-byte loads (two points per lane), four of them in flight per array before any math
         const double2* x2 = reinterpret_cast<const double2*>(x + base);
@@ -113,9 +86,8 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                uint64_t i = base + 2ull * (p0 + u * kThreads);
-                unsigned ka = handle(i, xs[u].x, ys[u].x);
-                unsigned kb = handle(i + 1, xs[u].y, ys[u].y);
+                unsigned ka = handle(xs[u].x, ys[u].x);
+                unsigned kb = handle(xs[u].y, ys[u].y);
                 k2[p0 + u * kThreads] = make_uint2(ka, kb);
             }
         }
@@ -123,7 +95,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
             uint64_t i = base + k;
             if (i >= n) break;
-            keys[i] = handle(i, x[i], y[i]);
+            keys[i] = handle(x[i], y[i]);
         }
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
@@ -139,15 +111,11 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
 }
 
 // ---- scan: bin starts + work items ------------------------------------------------------------
-// items: {bin, first record, record count, shared flag}; a bin's records are split into items of
-// at most kItemRecords so that one hot bin cannot serialize the launch on one CU.
-struct Item {
-    unsigned bin, first, count, shared;
-};
-
+// A bin's records are split into items of at most item_records so that one hot bin cannot
+// serialize the launch on one CU.
 __global__ void __launch_bounds__(kThreads)
-k_bin_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restrict__ bin_start,
-           unsigned* __restrict__ cursor, Item* __restrict__ items, unsigned* __restrict__ n_items) {
+k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_count,
+           unsigned* __restrict__ cursor, BinItem* __restrict__ items, unsigned* __restrict__ n_items) {
     __shared__ unsigned part[kThreads];
     __shared__ unsigned ipart[kThreads];
     const int per = (nbins + kThreads - 1) / kThreads;
@@ -156,13 +124,12 @@ k_bin_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restri
     for (int i = lo; i < hi; ++i) {
         unsigned c = bin_count[i];
         s += c;
-        it += (c + kItemRecords - 1) / kItemRecords;
+        it += (c + item_records - 1) / item_records;
     }
     part[threadIdx.x] = s;
     ipart[threadIdx.x] = it;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int off = 1; off < kThreads; off <<= 1) {
+    for (int off = 1; off < kThreads; off <<= 1) {             // Hillis-Steele inclusive scan
         unsigned a = 0, c2 = 0;
         if ((int)threadIdx.x >= off) { a = part[threadIdx.x - off]; c2 = ipart[threadIdx.x - off]; }
         __syncthreads();
@@ -170,34 +137,31 @@ k_bin_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restri
         ipart[threadIdx.x] += c2;
         __syncthreads();
     }
-    unsigned run = part[threadIdx.x] - s;        // exclusive prefixes of this thread's span
+    unsigned run = part[threadIdx.x] - s;                       // exclusive prefixes of this thread's span
     unsigned irun = ipart[threadIdx.x] - it;
     for (int i = lo; i < hi; ++i) {
         unsigned c = bin_count[i];
-        bin_start[i] = run;
         cursor[i] = run;
-        unsigned pieces = (c + kItemRecords - 1) / kItemRecords;
+        unsigned pieces = (c + item_records - 1) / item_records;
         for (unsigned p = 0; p < pieces; ++p) {
-            unsigned first = run + p * kItemRecords;
-            unsigned cnt = min((unsigned)kItemRecords, c - p * kItemRecords);
-            items[irun + p] = Item{(unsigned)i, first, cnt, pieces > 1 ? 1u : 0u};
+            unsigned first = run + p * item_records;
+            unsigned cnt = min(item_records, c - p * item_records);
+            items[irun + p] = BinItem{(unsigned)i, first, cnt, pieces > 1 ? 1u : 0u};
         }
         run += c;
         irun += pieces;
     }
-    if (threadIdx.x == kThreads - 1) {
-        bin_start[nbins] = part[threadIdx.x];
-        *n_items = ipart[threadIdx.x];
-    }
+    if (threadIdx.x == kThreads - 1) *n_items = ipart[threadIdx.x];
 }
 
 // ---- pass B: scatter records, staged through LDS so that every bin's run is written contiguously
 // VEC: every block of the launch is a full chunk and keys/v are 16-byte aligned (16-byte loads,
 // four consecutive points per lane); the ragged last chunk is a second, scalar launch.
-template <int PER_THREAD, bool VEC>
+// INDEX: record.y = index of the point instead of its value.
+template <int PER_THREAD, bool VEC, bool INDEX>
 __global__ void __launch_bounds__(kThreads)
 k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, const float* __restrict__ v,
-              uint64_t n, unsigned* __restrict__ cursor, Record* __restrict__ records) {
+              uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
     extern __shared__ unsigned char lds_raw[];
     // layout: stage[chunk] (8 B each) | hist[nbins] | loff[nbins] | gbase[nbins]
     uint2* stage = reinterpret_cast<uint2*>(lds_raw);
@@ -210,37 +174,41 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     __syncthreads();
 
     const uint64_t base = (uint64_t)(blockIdx.x + first_block) * b.chunk;
-    unsigned key[PER_THREAD], rank[PER_THREAD];
-    float val[PER_THREAD];
+    unsigned key[PER_THREAD], rank[PER_THREAD], val[PER_THREAD];
     if (VEC) {
-        // 16-byte loads: four consecutive points per lane per load
         const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
-        const float4* v4 = reinterpret_cast<const float4*>(v + base);
+        const uint4* v4 = reinterpret_cast<const uint4*>(v + base);
 #pragma unroll
         for (int q = 0; q < PER_THREAD / 4; ++q) {
-            uint4 kk = k4[q * kThreads + threadIdx.x];
-            float4 vv = v ? v4[q * kThreads + threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned p = q * kThreads + threadIdx.x;
+            uint4 kk = k4[p];
             key[4 * q + 0] = kk.x; key[4 * q + 1] = kk.y; key[4 * q + 2] = kk.z; key[4 * q + 3] = kk.w;
-            val[4 * q + 0] = vv.x; val[4 * q + 1] = vv.y; val[4 * q + 2] = vv.z; val[4 * q + 3] = vv.w;
+            if (INDEX) {
+                unsigned i0 = (unsigned)base + 4u * p;
+                val[4 * q + 0] = i0; val[4 * q + 1] = i0 + 1; val[4 * q + 2] = i0 + 2; val[4 * q + 3] = i0 + 3;
+            } else {
+                uint4 vv = v ? v4[p] : make_uint4(0u, 0u, 0u, 0u);
+                val[4 * q + 0] = vv.x; val[4 * q + 1] = vv.y; val[4 * q + 2] = vv.z; val[4 * q + 3] = vv.w;
+            }
         }
-#pragma unroll
-        for (int k = 0; k < PER_THREAD; ++k) rank[k] = 0;
     } else {
 #pragma unroll
         for (int k = 0; k < PER_THREAD; ++k) {
             uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
             key[k] = 0xFFFFFFFFu;
-            rank[k] = 0;
-            val[k] = 0.0f;
+            val[k] = 0u;
             if (i < n) {
                 key[k] = keys[i];
-                if (v) val[k] = v[i];
+                if (INDEX) val[k] = (unsigned)i;
+                else if (v) val[k] = __float_as_uint(v[i]);
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k)
+    for (int k = 0; k < PER_THREAD; ++k) {
+        rank[k] = 0;
         if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);   // rank inside (block, bin)
+    }
     __syncthreads();
 
     // block-wide exclusive scan of hist -> loff; reserve global ranges per non-empty bin
@@ -248,7 +216,6 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     const int lo = threadIdx.x * per, hi = min(lo + per, b.nbins);
     unsigned s = 0;
     for (int i = lo; i < hi; ++i) s += hist[i];
-    // wave scan
     unsigned incl = s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -276,7 +243,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     for (int k = 0; k < PER_THREAD; ++k) {
         if (key[k] != 0xFFFFFFFFu) {
             unsigned bin = key[k] >> kLcellBits;
-            stage[loff[bin] + rank[k]] = make_uint2(key[k], __float_as_uint(val[k]));
+            stage[loff[bin] + rank[k]] = make_uint2(key[k], val[k]);
         }
     }
     __syncthreads();
@@ -286,12 +253,11 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
         uint2 rec = stage[j];
         unsigned bin = rec.x >> kLcellBits;
         unsigned dst = gbase[bin] + (j - loff[bin]);
-        reinterpret_cast<uint2*>(records)[dst] = make_uint2(rec.x & kLcellMask, rec.y);
+        records[dst] = make_uint2(rec.x & kLcellMask, rec.y);
     }
 }
 
-// ---- pass C: fold a work item's records into an LDS tile, merge the tile into the state planes
-// ---- pass C: fold a work item's records into an LDS tile, merge the tile into the state planes
+// ---- pass C (Point glyph): fold a work item's records into an LDS tile, merge into the planes ---
 //
 // LDS atomics on gfx950 (tools/ubench_lds_atomics*.hip, measured): ds_add_f32 costs ~194 cycles
 // per wave-instruction per CU whatever the addresses (lanes are serialized); ds_add_u32 / ds_max_i32
@@ -300,28 +266,37 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
 //   weight -> u32,    ds_add_u32  (a Point-glyph weight is 1; exact)
 //   max/min-> f32 bits, integer ds_max/ds_min (common.hpp)
 // and is rounded to f32 once, when it is merged into the f32 state planes.
-constexpr int kBytesSum = 8, kBytesWgt = 4, kBytesMax = 4, kBytesMin = 4;
+inline int tile_cell_bytes(unsigned mask) {
+    return ((mask & 1) ? 8 : 0) + ((mask & 2) ? 4 : 0) + ((mask & 4) ? 4 : 0) + ((mask & 8) ? 4 : 0);
+}
 
-__host__ __device__ inline int tile_cell_bytes(unsigned mask) {
-    return ((mask & 1) ? kBytesSum : 0) + ((mask & 2) ? kBytesWgt : 0) + ((mask & 4) ? kBytesMax : 0) +
-           ((mask & 8) ? kBytesMin : 0);
+// LDS tile shape: 128 columns x as many rows (multiple of 8, <= 128) as fit ~150 KB of the CU's
+// 160 KB LDS at the per-cell footprint of the requested planes.
+inline BinGeom point_bin_geom(const GridDev& g, uint32_t mask) {
+    BinGeom b;
+    b.tile_w = 128;
+    b.tile_h = std::min(128, (150 * 1024 / (std::max(tile_cell_bytes(mask), 4) * 128)) & ~7);
+    b.bins_x = (g.W + b.tile_w - 1) / b.tile_w;
+    b.bins_y = (g.st_rows + b.tile_h - 1) / b.tile_h;
+    b.nbins = b.bins_x * b.bins_y;
+    b.chunk = b.nbins <= 2048 ? 16384 : 8192;
+    return b;
 }
 
 template <unsigned MASK>
 __global__ void __launch_bounds__(kThreads)
-k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const Record* __restrict__ records,
-             const Item* __restrict__ items, const unsigned* __restrict__ n_items) {
+k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ records,
+             const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
     extern __shared__ double lds_tile[];
     if (blockIdx.x >= *n_items) return;
-    const Item it = items[blockIdx.x];
+    const BinItem it = items[blockIdx.x];
     const int cells = b.tile_w * b.tile_h;                     // multiple of 1024
     double* t_sum = lds_tile;
     unsigned* t_wgt = reinterpret_cast<unsigned*>(t_sum + ((MASK & 1) ? cells : 0));
     float* t_max = reinterpret_cast<float*>(t_wgt + ((MASK & 2) ? cells : 0));
     float* t_min = t_max + ((MASK & 4) ? cells : 0);
 
-    // identity fill
-    for (int i = threadIdx.x; i < cells; i += kThreads) {
+    for (int i = threadIdx.x; i < cells; i += kThreads) {      // identity fill
         if (MASK & 1) t_sum[i] = 0.0;
         if (MASK & 2) t_wgt[i] = 0u;
         if (MASK & 4) t_max[i] = -FLT_MAX;
@@ -332,7 +307,7 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const Record* __restrict__ reco
     // records: kUnroll independent 8-byte loads in flight per lane (64 KB per CU) ahead of the
     // dependent LDS atomics
     constexpr int kUnroll = 8;
-    const uint2* rec = reinterpret_cast<const uint2*>(records) + it.first;
+    const uint2* rec = records + it.first;
     for (unsigned j0 = threadIdx.x; j0 < it.count; j0 += kUnroll * kThreads) {
         uint2 r[kUnroll];
 #pragma unroll
@@ -413,13 +388,12 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const Record* __restrict__ reco
 }
 
 template <unsigned MASK>
-void launch_accum(pcr_hip_engine* e, const BinGeom& b, const PlanesDev& pl, const Record* rec,
-                  const Item* items, const unsigned* n_items, int max_items) {
+void launch_accum(pcr_hip_engine* e, const BinGeom& b, const PlanesDev& pl, const BinBuffers& bb) {
     size_t lds = (size_t)b.tile_w * b.tile_h * tile_cell_bytes(MASK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_accum<MASK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(max_items), dim3(kThreads), lds, e->stream, e->gd, b, pl,
-                       rec, items, n_items);
+    hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, b, pl,
+                       bb.records, bb.items, bb.n_items);
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -428,41 +402,30 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 namespace pcrhip {
 
-bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask) {
-    if (mask == 0 || (mask & ~15u)) return false;
-    BinGeom b = bin_geom(e->gd, mask);
-    if (b.nbins > kMaxBins) return false;
-    // not worth the fixed cost of sweeping every tile for a handful of points
-    uint64_t cells = (uint64_t)e->gd.W * e->gd.st_rows;
-    if (e->forced_path != 2 && e->stats.points_in * 16 < cells) return false;
-    return e->stats.points_in < (1ull << 32) - (1ull << 20);
-}
-
-int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
-                 const double* x, const double* y, const float* v, uint64_t n) {
-    const BinGeom b = bin_geom(e->gd, mask);
+int bin_points(pcr_hip_engine* e, const BinGeom& b, const double* x, const double* y, const float* v,
+               uint64_t n, bool index_records, unsigned item_records, BinBuffers* out,
+               size_t extra_scratch, void** extra) {
     const int blocks = (int)((n + b.chunk - 1) / b.chunk);
-    const int max_items = b.nbins + (int)(n / kItemRecords) + 1;
+    const int max_items = b.nbins + (int)(n / item_records) + 1;
 
-    // scratch carve-up
-    size_t off = 0;
+    size_t off = 0;                                             // scratch carve-up
     const size_t o_count = off;  off += align256((size_t)b.nbins * 4);
-    const size_t o_start = off;  off += align256((size_t)(b.nbins + 1) * 4);
     const size_t o_cursor = off; off += align256((size_t)b.nbins * 4);
     const size_t o_nitems = off; off += 256;
-    const size_t o_items = off;  off += align256((size_t)max_items * sizeof(Item));
-    const size_t o_rec = off;    off += align256((size_t)n * sizeof(Record));
+    const size_t o_items = off;  off += align256((size_t)max_items * sizeof(BinItem));
+    const size_t o_rec = off;    off += align256((size_t)n * sizeof(uint2));
     const size_t o_keys = off;   off += align256((size_t)n * sizeof(unsigned));
+    const size_t o_extra = off;  off += align256(extra_scratch);
     int rc = ensure_scratch(e, off);
     if (rc) return rc;
     char* s = e->d_scratch;
     unsigned* d_count = reinterpret_cast<unsigned*>(s + o_count);
-    unsigned* d_start = reinterpret_cast<unsigned*>(s + o_start);
     unsigned* d_cursor = reinterpret_cast<unsigned*>(s + o_cursor);
     unsigned* d_nitems = reinterpret_cast<unsigned*>(s + o_nitems);
-    Item* d_items = reinterpret_cast<Item*>(s + o_items);
-    Record* d_rec = reinterpret_cast<Record*>(s + o_rec);
+    BinItem* d_items = reinterpret_cast<BinItem*>(s + o_items);
+    uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
     unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
+    if (extra) *extra = s + o_extra;
 
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     {
@@ -472,13 +435,13 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, d_count, d_start,
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, item_records, d_count,
                            d_cursor, d_items, d_nitems);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scatter");
-        size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 3;
-        const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;        // d_keys is 256-byte aligned
+        const size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 3;
+        const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;   // d_keys is 256-B aligned
         const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
         auto launch = [&](auto kernel, int nblocks, int first) {
             if (nblocks <= 0) return;
@@ -487,18 +450,48 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
             hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, b, first, d_keys, v, n,
                                d_cursor, d_rec);
         };
-        if (b.chunk == 16384) {
-            launch(&k_bin_scatter<16, true>, full_blocks, 0);
-            launch(&k_bin_scatter<16, false>, blocks - full_blocks, full_blocks);
+        if (b.chunk == 16384 && !index_records) {
+            launch(&k_bin_scatter<16, true, false>, full_blocks, 0);
+            launch(&k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
+        } else if (b.chunk == 16384) {
+            launch(&k_bin_scatter<16, true, true>, full_blocks, 0);
+            launch(&k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
+        } else if (!index_records) {
+            launch(&k_bin_scatter<8, true, false>, full_blocks, 0);
+            launch(&k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
         } else {
-            launch(&k_bin_scatter<8, true>, full_blocks, 0);
-            launch(&k_bin_scatter<8, false>, blocks - full_blocks, full_blocks);
+            launch(&k_bin_scatter<8, true, true>, full_blocks, 0);
+            launch(&k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
         }
     }
+    PCR_HIP_TRY(hipGetLastError());
+    out->records = d_rec;
+    out->items = d_items;
+    out->n_items = d_nitems;
+    out->max_items = max_items;
+    return PCR_HIP_OK;
+}
+
+bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask) {
+    if (mask == 0 || (mask & ~15u)) return false;
+    BinGeom b = point_bin_geom(e->gd, mask);
+    if (b.nbins > kMaxBins) return false;
+    // not worth the fixed cost of sweeping every tile for a handful of points
+    uint64_t cells = (uint64_t)e->gd.W * e->gd.st_rows;
+    if (e->forced_path != 2 && e->stats.points_in * 16 < cells) return false;
+    return e->stats.points_in < (1ull << 32) - (1ull << 20);
+}
+
+int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
+                 const double* x, const double* y, const float* v, uint64_t n) {
+    const BinGeom b = point_bin_geom(e->gd, mask);
+    BinBuffers bb{};
+    int rc = bin_points(e, b, x, y, v, n, false, kPointItemRecords, &bb);
+    if (rc) return rc;
     {
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {
-#define PCR_ACC(M) case M: launch_accum<M>(e, b, pl, d_rec, d_items, d_nitems, max_items); break;
+#define PCR_ACC(M) case M: launch_accum<M>(e, b, pl, bb); break;
             PCR_ACC(1) PCR_ACC(2) PCR_ACC(3) PCR_ACC(4) PCR_ACC(5) PCR_ACC(6) PCR_ACC(7) PCR_ACC(8)
             PCR_ACC(9) PCR_ACC(10) PCR_ACC(11) PCR_ACC(12) PCR_ACC(13) PCR_ACC(14) PCR_ACC(15)
 #undef PCR_ACC
@@ -512,12 +505,6 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     e->stats.lds_apron = 0;
     e->stats.num_bins = b.nbins;
     return PCR_HIP_OK;
-}
-
-bool binned_glyph_supported(const pcr_hip_engine*, const GlyphDev&, uint32_t) { return false; }
-int binned_glyph(pcr_hip_engine*, const GlyphDev&, uint32_t, const PlanesDev&, const double*, const double*,
-                 const float*, uint64_t) {
-    return fail(PCR_HIP_NOT_IMPLEMENTED, "binned glyph path not built");
 }
 
 }  // namespace pcrhip

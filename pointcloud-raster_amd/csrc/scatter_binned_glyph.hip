@@ -1,0 +1,284 @@
+// scatter_binned_glyph.hip -- Gaussian / Line glyphs on LDS tiles.
+//
+// Points are binned by the LDS tile that contains their CENTRE cell (bin_points, index records).
+// One workgroup per work item keeps an LDS window = the bin's interior plus an apron of A cells
+// on every side, paints its points' footprints into it with LDS atomics (ds_add_f64 for the
+// v*w and w sums of the Gaussian, ds_add_f64 + ds_add_u32 for the Line -- ds_add_f32 is ~28x
+// slower on gfx950, see scatter_binned.hip), then merges the window into the HBM planes with
+// float atomics, shaped as contiguous row segments (aprons of neighbouring bins overlap, so the
+// merge cannot be a plain store).  A footprint cell that falls outside the window (radius larger
+// than the apron the LDS can afford) goes straight to a global atomic: correct for any radius,
+// fast when the apron covers it.
+//
+// Replaces kernel_glyph_gaussian / kernel_glyph_line (src/engine/glyph_kernels.cu:345-492);
+// arithmetic follows the CPU reference (glyph_device.hpp).
+#include "engine.hpp"
+#include "glyph_device.hpp"
+
+using namespace pcrhip;
+
+namespace {
+
+constexpr int kThreads = 1024;
+
+struct GlyphTile {
+    BinGeom bins;       // interior = bins.tile_w x bins.tile_h
+    int apron;          // LDS apron, cells
+    int lw, lh;         // LDS window = interior + 2 * apron
+    int need;           // apron the glyph spec can need (>= apron when the LDS could not afford it)
+};
+
+// ---- sinks ---------------------------------------------------------------------------------------
+// Gaussian: both sums are double in LDS.
+template <unsigned MASK>
+struct GaussLdsSink {
+    const GridDev& g;
+    PlanesDev pl;
+    double* t_s;
+    double* t_w;
+    int x0, y0, lw, lh;            // window origin in GLOBAL cell coordinates
+    __device__ __forceinline__ void add(int row, int col, float vw, float w) {
+        int lx = col - x0, ly = row - y0;
+        if ((unsigned)lx < (unsigned)lw && (unsigned)ly < (unsigned)lh) {
+            int li = ly * lw + lx;
+            if (MASK & PCR_HIP_PLANE_SUM) unsafeAtomicAdd(&t_s[li], (double)vw);
+            if (MASK & PCR_HIP_PLANE_WGT) unsafeAtomicAdd(&t_w[li], (double)w);
+        } else {
+            int64_t cell = (int64_t)(row - g.st_r0) * g.W + col;
+            if (MASK & PCR_HIP_PLANE_SUM) atomic_add_f32(pl.sum + cell, vw);
+            if (MASK & PCR_HIP_PLANE_WGT) atomic_add_f32(pl.wgt + cell, w);
+        }
+    }
+};
+
+// Line: weight is 1 per visited cell -> integer count.
+template <unsigned MASK>
+struct LineLdsSink {
+    const GridDev& g;
+    PlanesDev pl;
+    double* t_s;
+    unsigned* t_c;
+    int x0, y0, lw, lh;
+    __device__ __forceinline__ void add(int row, int col, float vw, float) {
+        int lx = col - x0, ly = row - y0;
+        if ((unsigned)lx < (unsigned)lw && (unsigned)ly < (unsigned)lh) {
+            int li = ly * lw + lx;
+            if (MASK & PCR_HIP_PLANE_SUM) unsafeAtomicAdd(&t_s[li], (double)vw);
+            if (MASK & PCR_HIP_PLANE_WGT) atomicAdd(&t_c[li], 1u);
+        } else {
+            int64_t cell = (int64_t)(row - g.st_r0) * g.W + col;
+            if (MASK & PCR_HIP_PLANE_SUM) atomic_add_f32(pl.sum + cell, vw);
+            if (MASK & PCR_HIP_PLANE_WGT) atomic_add_f32(pl.wgt + cell, 1.0f);
+        }
+    }
+};
+
+// ---- Gaussian tiles ---------------------------------------------------------------------------------
+template <unsigned MASK>
+__global__ void __launch_bounds__(kThreads)
+k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __restrict__ records,
+             const BinItem* __restrict__ items, const unsigned* __restrict__ n_items,
+             const double* __restrict__ x, const double* __restrict__ y, const float* __restrict__ v) {
+    extern __shared__ double lds_win[];
+    if (blockIdx.x >= *n_items) return;
+    const BinItem it = items[blockIdx.x];
+    const int cells = t.lw * t.lh;
+    double* t_s = lds_win;
+    double* t_w = t_s + ((MASK & 1) ? cells : 0);
+    for (int i = threadIdx.x; i < cells * (((MASK & 1) ? 1 : 0) + ((MASK & 2) ? 1 : 0)); i += kThreads) lds_win[i] = 0.0;
+    __syncthreads();
+
+    const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
+    GaussLdsSink<MASK> sink{g, pl, t_s, t_w, bx * t.bins.tile_w - t.apron,
+                            g.st_r0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
+
+    // each wave takes 64 of the item's points at a time: one lane prepares one point, then all
+    // 64 lanes paint the points one after the other
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint2* rec = records + it.first;
+    for (unsigned j0 = wave * 64; j0 < it.count; j0 += kThreads) {
+        unsigned j = j0 + lane;
+        bool valid = j < it.count;
+        GaussParams q{};
+        if (valid) {
+            uint64_t i = rec[j].y;
+            PointGeom pg = point_geom(g, x[i], y[i]);
+            valid = pg.valid;                     // always true for a binned point; keeps q sane
+            if (valid) q = gauss_params(g, gl, pg, v[i], i);
+        }
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            GaussParams u = lane_bcast(q, src);
+            gauss_splat_wave(u, lane, sink);
+        }
+    }
+    __syncthreads();
+
+    // merge: window -> planes with float atomics, consecutive lanes on consecutive cells of a row
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        double s = (MASK & 1) ? t_s[i] : 0.0;
+        double w = (MASK & 2) ? t_w[i] : 0.0;
+        if (s == 0.0 && w == 0.0) continue;
+        int ly = i / t.lw, lx = i - ly * t.lw;
+        int col = sink.x0 + lx, row = sink.y0 + ly;          // non-zero cells were clipped to the grid already
+        int64_t cell = (int64_t)(row - g.st_r0) * g.W + col;
+        if ((MASK & 1) && s != 0.0) atomic_add_f32(pl.sum + cell, (float)s);
+        if ((MASK & 2) && w != 0.0) atomic_add_f32(pl.wgt + cell, (float)w);
+    }
+}
+
+// ---- Line tiles ---------------------------------------------------------------------------------------
+template <unsigned MASK>
+__global__ void __launch_bounds__(kThreads)
+k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __restrict__ records,
+            const BinItem* __restrict__ items, const unsigned* __restrict__ n_items,
+            const double* __restrict__ x, const double* __restrict__ y, const float* __restrict__ v) {
+    extern __shared__ double lds_win[];
+    if (blockIdx.x >= *n_items) return;
+    const BinItem it = items[blockIdx.x];
+    const int cells = t.lw * t.lh;                           // even (lw, lh even)
+    double* t_s = lds_win;
+    unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        if (MASK & 1) t_s[i] = 0.0;
+        if (MASK & 2) t_c[i] = 0u;
+    }
+    __syncthreads();
+
+    const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
+    LineLdsSink<MASK> sink{g, pl, t_s, t_c, bx * t.bins.tile_w - t.apron,
+                           g.st_r0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
+    const uint2* rec = records + it.first;
+    for (unsigned j = threadIdx.x; j < it.count; j += kThreads) {
+        uint64_t i = rec[j].y;
+        PointGeom pg = point_geom(g, x[i], y[i]);
+        if (!pg.valid) continue;
+        LineParams q = line_params(g, gl, pg, v[i], i);
+        line_walk(q, sink);
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        double s = (MASK & 1) ? t_s[i] : 0.0;
+        unsigned c = (MASK & 2) ? t_c[i] : 0u;
+        if (s == 0.0 && c == 0u) continue;
+        int ly = i / t.lw, lx = i - ly * t.lw;
+        int64_t cell = (int64_t)(sink.y0 + ly - g.st_r0) * g.W + (sink.x0 + lx);
+        if ((MASK & 1) && s != 0.0) atomic_add_f32(pl.sum + cell, (float)s);
+        if ((MASK & 2) && c) atomic_add_f32(pl.wgt + cell, (float)c);
+    }
+}
+
+// ---- host: tile geometry from the glyph spec ---------------------------------------------------------
+int apron_needed(const GridDev& g, const GlyphDev& gl) {
+    double cap = std::min<double>(std::max(gl.max_radius, 0.0f), 4096.0);
+    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
+        if (gl.sigma_x || gl.sigma_y) return (int)std::ceil(cap);
+        float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
+        float R = std::min(3.0f * std::max(sx, sy), gl.max_radius);
+        if (!(R >= 0.0f)) return 0;
+        return (int)std::ceil(std::min<double>(R, 4096.0));
+    }
+    // Line: reach of the rounded end points
+    if (gl.half_length) return (int)std::ceil(cap) + 1;
+    double hx = std::min<double>(std::fabs(gl.def_half_length * (float)g.inv_csx), 4096.0);
+    double hy = std::min<double>(std::fabs(gl.def_half_length * (float)g.inv_csy), 4096.0);
+    if (gl.def_half_length * (float)g.inv_csx > gl.max_radius) hx = cap;       // std::min(h, cap) caps positive h only
+    if (gl.def_half_length * (float)g.inv_csy > gl.max_radius) hy = cap;
+    return (int)std::ceil(std::max(hx, hy)) + 1;
+}
+
+int cell_bytes(int glyph_type, unsigned mask) {
+    if (glyph_type == PCR_HIP_GLYPH_GAUSSIAN) return ((mask & 1) ? 8 : 0) + ((mask & 2) ? 8 : 0);
+    return ((mask & 1) ? 8 : 0) + ((mask & 2) ? 4 : 0);
+}
+
+bool glyph_tile(const GridDev& g, const GlyphDev& gl, unsigned mask, GlyphTile* out) {
+    const int limit = 150 * 1024 / std::max(cell_bytes(gl.type, mask), 4);    // LDS cells per workgroup
+    const int side = ((int)std::floor(std::sqrt((double)limit))) & ~1;
+    const int need = apron_needed(g, gl);
+    int S = std::min(128, (side - 2 * need) & ~7);
+    if (S < 32) S = 32;
+    // bins must fit the binning passes' LDS histogram
+    auto nbins_for = [&](int s) { return ((g.W + s - 1) / s) * ((g.st_rows + s - 1) / s); };
+    while (nbins_for(S) > kMaxBins && S < side - 8) S += 8;
+    if (nbins_for(S) > kMaxBins) return false;
+    GlyphTile t;
+    t.need = need;
+    t.apron = std::max(0, std::min(need, (side - S) / 2));
+    t.lw = S + 2 * t.apron;
+    t.lh = S + 2 * t.apron;
+    t.bins.tile_w = S;
+    t.bins.tile_h = S;
+    t.bins.bins_x = (g.W + S - 1) / S;
+    t.bins.bins_y = (g.st_rows + S - 1) / S;
+    t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
+    t.bins.chunk = t.bins.nbins <= 2048 ? 16384 : 8192;
+    *out = t;
+    return true;
+}
+
+template <typename K>
+void launch_tile(K kernel, pcr_hip_engine* e, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
+                 const BinBuffers& bb, size_t lds, const double* x, const double* y, const float* v) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, gl, t, pl, bb.records,
+                       bb.items, bb.n_items, x, y, v);
+}
+
+}  // namespace
+
+namespace pcrhip {
+
+bool binned_glyph_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask) {
+    if (mask == 0 || (mask & ~3u)) return false;
+    if (gl.type != PCR_HIP_GLYPH_GAUSSIAN && gl.type != PCR_HIP_GLYPH_LINE) return false;
+    GlyphTile t;
+    if (!glyph_tile(e->gd, gl, mask, &t)) return false;
+    // every bin's window is swept once per scatter: not worth it for a handful of points
+    uint64_t cells = (uint64_t)e->gd.W * e->gd.st_rows;
+    if (e->forced_path != 2 && e->stats.points_in * 64 < cells) return false;
+    return e->stats.points_in < (1ull << 32) - (1ull << 20);
+}
+
+int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
+                 const double* x, const double* y, const float* v, uint64_t n) {
+    GlyphTile t;
+    if (!glyph_tile(e->gd, gl, mask, &t)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: grid cannot be binned");
+    // work item size: ~4 M cell updates per workgroup for the Gaussian, 64 K segments for the Line
+    unsigned item_points = 65536;
+    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
+        double fp = (2.0 * t.need + 1.0) * (2.0 * t.need + 1.0);
+        item_points = (unsigned)std::min(65536.0, std::max(1024.0, 4.0e6 / fp));
+    }
+    BinBuffers bb{};
+    int rc = bin_points(e, t.bins, x, y, nullptr, n, true, item_points, &bb);
+    if (rc) return rc;
+    const size_t lds = (size_t)t.lw * t.lh * cell_bytes(gl.type, mask);
+    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
+        ScopedKernelTimer tm(e, "k_tile_gauss");
+        switch (mask) {
+            case 1: launch_tile(&k_tile_gauss<1>, e, gl, t, pl, bb, lds, x, y, v); break;
+            case 2: launch_tile(&k_tile_gauss<2>, e, gl, t, pl, bb, lds, x, y, v); break;
+            default: launch_tile(&k_tile_gauss<3>, e, gl, t, pl, bb, lds, x, y, v); break;
+        }
+    } else {
+        ScopedKernelTimer tm(e, "k_tile_line");
+        switch (mask) {
+            case 1: launch_tile(&k_tile_line<1>, e, gl, t, pl, bb, lds, x, y, v); break;
+            case 2: launch_tile(&k_tile_line<2>, e, gl, t, pl, bb, lds, x, y, v); break;
+            default: launch_tile(&k_tile_line<3>, e, gl, t, pl, bb, lds, x, y, v); break;
+        }
+    }
+    PCR_HIP_TRY(hipGetLastError());
+    e->stats.path = 1;
+    e->stats.lds_tile_w = t.bins.tile_w;
+    e->stats.lds_tile_h = t.bins.tile_h;
+    e->stats.lds_apron = t.apron;
+    e->stats.num_bins = t.bins.nbins;
+    return PCR_HIP_OK;
+}
+
+}  // namespace pcrhip

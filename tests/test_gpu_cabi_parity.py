@@ -23,7 +23,7 @@ import cases  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 RT = {"Sum": 0, "Max": 1, "Min": 2, "Average": 3, "WeightedAverage": 4, "Count": 5}
-PATHS = [1, 0]        # glyphs: direct, auto
+PATHS = [1, 2, 0]     # glyphs: direct, forced binned LDS tiles, auto
 POINT_PATHS = [1, 2, 0]  # Point glyph: direct, forced binned LDS tiles, auto
 
 
