@@ -107,12 +107,8 @@ __device__ __forceinline__ float gauss_weight(const GaussParams& q, int dx, int 
 // enumerated row-major, 64 cells per step, so consecutive lanes hit consecutive cells
 // of a row (contiguous atomics).  q must be wave-uniform.
 template <typename Sink>
-__device__ __forceinline__ void gauss_splat_wave(const GaussParams& q, int lane, Sink& sink) {
-    // intersect the window with the clip rectangle first: no lane iterates outside it
-    int x0 = max(q.icx - q.r, q.cx0), x1 = min(q.icx + q.r + 1, q.cx1);
-    int y0 = max(q.icy - q.r, q.cy0), y1 = min(q.icy + q.r + 1, q.cy1);
-    int wdt = x1 - x0, hgt = y1 - y0;
-    if (wdt <= 0 || hgt <= 0) return;
+__device__ __forceinline__ void gauss_splat_generic(const GaussParams& q, int lane, Sink& sink,
+                                                    int x0, int y0, int wdt, int hgt) {
     int total = wdt * hgt;
     float inv_w = 1.0f / (float)wdt;
     const bool small = total < (1 << 18);                 // float row index exact below 2^21 cells
@@ -123,6 +119,89 @@ __device__ __forceinline__ void gauss_splat_wave(const GaussParams& q, int lane,
         float w = gauss_weight(q, gx - q.icx, gy - q.icy);
         if (w < 1e-6f) continue;                          // glyph_kernels.cu:166
         sink.add(gy, gx, q.val * w, w);
+    }
+}
+
+// One LANE paints one point: for footprints of a few dozen cells the per-point set-up of the
+// wave-cooperative form costs more than the cells themselves.  Same arithmetic as the reference
+// loop (glyph_kernels.cu:145-176); the row term is hoisted out of the column loop when the
+// footprint is axis-aligned (exact: rxr == rdx, ryr == rdy there).
+template <typename Sink>
+__device__ __forceinline__ void gauss_splat_lane(const GaussParams& q, Sink& sink) {
+    int x0 = max(q.icx - q.r, q.cx0), x1 = min(q.icx + q.r + 1, q.cx1);
+    int y0 = max(q.icy - q.r, q.cy0), y1 = min(q.icy + q.r + 1, q.cy1);
+    const bool axis_aligned = (q.cos_r == 1.0f) && (q.sin_r == 0.0f);
+    for (int gy = y0; gy < y1; ++gy) {
+        const float rdy = (float)(gy - q.icy) - q.sub_cy;
+        const float by = rdy / q.sy;
+        const float b2 = by * by;
+        for (int gx = x0; gx < x1; ++gx) {
+            float w;
+            if (axis_aligned) {
+                const float rdx = (float)(gx - q.icx) - q.sub_cx;
+                const float a = rdx / q.sx;
+                w = expf(-0.5f * (a * a + b2));
+            } else {
+                w = gauss_weight(q, gx - q.icx, gy - q.icy);
+            }
+            if (w < 1e-6f) continue;
+            sink.add(gy, gx, q.val * w, w);
+        }
+    }
+}
+
+// One WAVE paints one point (q wave-uniform).
+//
+// Axis-aligned footprints (rotation 0: cos == 1, sin == 0, the default) are evaluated without any
+// per-cell division: with no rotation rxr == rdx and ryr == rdy exactly, so (rxr/sx)^2 depends
+// only on the column and (ryr/sy)^2 only on the row.  Lanes are laid out as G rows x wdt columns
+// (G = 64 / wdt); each lane keeps its column's a^2 for the whole point (one true division per
+// lane per point), the row terms b^2 are computed once per 64-row block (one division per lane)
+// and fetched per step with ds_bpermute.  The weight is then the reference's own expression
+// exp(-0.5f * (a*a + b*b)) with identically rounded operands.
+// Rotated or very wide (> 192 columns after clipping) footprints use the generic loop.
+template <typename Sink>
+__device__ __forceinline__ void gauss_splat_wave(const GaussParams& q, int lane, Sink& sink) {
+    // intersect the window with the clip rectangle first: no lane iterates outside it
+    int x0 = max(q.icx - q.r, q.cx0), x1 = min(q.icx + q.r + 1, q.cx1);
+    int y0 = max(q.icy - q.r, q.cy0), y1 = min(q.icy + q.r + 1, q.cy1);
+    int wdt = x1 - x0, hgt = y1 - y0;
+    if (wdt <= 0 || hgt <= 0) return;
+    const bool axis_aligned = (q.cos_r == 1.0f) && (q.sin_r == 0.0f);
+    if (!axis_aligned || wdt > 192) {
+        gauss_splat_generic(q, lane, sink, x0, y0, wdt, hgt);
+        return;
+    }
+    const bool narrow = wdt <= 64;
+    const int G = narrow ? 64 / wdt : 1;                               // rows per step
+    // g = lane / wdt, c = lane % wdt for lane < 64 (exact: lane * (ceil(2^16/wdt)*wdt - 2^16) < 2^16)
+    const int magic = (65536 + wdt - 1) / wdt;
+    const int g = narrow ? (lane * magic) >> 16 : 0;
+    const int c_in = narrow ? lane - g * wdt : lane;
+    const bool lane_used = narrow ? (g < G) : true;
+    const int ncb = narrow ? 1 : (wdt + 63) >> 6;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int c = c_in + (cb << 6);
+        const bool col_ok = lane_used && c < wdt;
+        const int gx = x0 + c;
+        const float rdx = (float)(gx - q.icx) - q.sub_cx;
+        const float a = rdx / q.sx;
+        const float a2 = a * a;
+        for (int rb = 0; rb < hgt; rb += 64) {
+            // row table: lane l holds (rdy/sy)^2 of row rb + l
+            const float rdy = (float)(y0 + rb + lane - q.icy) - q.sub_cy;
+            const float bt = rdy / q.sy;
+            const float b2t = bt * bt;
+            const int rows_here = min(64, hgt - rb);
+            for (int k = 0; k < rows_here; k += G) {
+                const int rloc = k + g;
+                const float b2 = __builtin_bit_cast(
+                    float, __builtin_amdgcn_ds_bpermute((rloc & 63) << 2, __builtin_bit_cast(int, b2t)));
+                const float w = expf(-0.5f * (a2 + b2));
+                if (col_ok && rloc < rows_here && !(w < 1e-6f))
+                    sink.add(y0 + rb + rloc, gx, q.val * w, w);
+            }
+        }
     }
 }
 

@@ -106,12 +106,18 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
             valid = pg.valid;                     // always true for a binned point; keeps q sane
             if (valid) q = gauss_params(g, gl, pg, v[i], i);
         }
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            GaussParams u = lane_bcast(q, src);
-            gauss_splat_wave(u, lane, sink);
+        // small footprints (<= 11 x 11): one lane per point; larger ones: the whole wave per point
+        const bool big = valid && q.r > 5;
+        if (!__any(big)) {
+            if (valid) gauss_splat_lane(q, sink);
+        } else {
+            unsigned long long todo = __ballot(valid);
+            while (todo) {
+                int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                GaussParams u = lane_bcast(q, src);
+                gauss_splat_wave(u, lane, sink);
+            }
         }
     }
     __syncthreads();
