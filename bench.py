@@ -220,9 +220,17 @@ def main():
             launches, ms = kernels[dom]
             avg_ms = ms / launches
             achieved = bpp * n / (avg_ms * 1e-3) / 1e9
+            traffic = None        # HBM bytes per launch of the dominant kernel, from committed rocprofv3 PMC runs
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pmc = json.load(f).get(args.workload, {})
+                if dom in pmc and pmc.get("points_per_launch") == n:
+                    traffic = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
+            except OSError:
+                pass
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "traffic": None, "avg_kernel_ms": round(avg_ms, 4),
+                               "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
                                "algorithmic_bytes_per_launch": bpp * n}
             out["kernels_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(kernels.items())}
         sample = args.cpu_sample
