@@ -128,6 +128,10 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "direct", "binned"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="points of the CPU baseline sample (0 = skip)")
     ap.add_argument("--host-result", action="store_true", help="finalize into host memory (PCIe-inclusive)")
+    ap.add_argument("--host-cloud", action="store_true", help="ingest a host-resident cloud (PCIe-inclusive)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --same-device rehearses the N > 1 code path on a one-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,9 +141,14 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     G, n = args.grid, args.points
     H = G * world                                          # rows: one G-row block per GPU
@@ -157,7 +166,9 @@ def main():
     y_hi = float(H - rank * G)
     y_lo = y_hi - G
     x, y, v, ch = make_points(args.workload, n, G, y_lo, y_hi, seed=42 + rank)
-    cloud = make_cloud(x, y, v, ch).to_device()
+    cloud = make_cloud(x, y, v, ch)
+    if not args.host_cloud:
+        cloud = cloud.to_device()
     del x, y, v, ch
 
     total = args.warmup + args.steps
@@ -184,7 +195,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -211,7 +222,8 @@ def main():
                        "grid": f"{G}x{H}", "rows_per_gpu": G, "glyph": glyph,
                        "reductions": [str(r.type).split(".")[-1] for r in cfg.reductions],
                        "scatter_path": info["path"], "lds_tile": list(info["lds_tile"]),
-                       "num_bins": info["num_bins"], "input": "device-resident",
+                       "num_bins": info["num_bins"],
+                       "input": "host-resident (H2D inside step)" if args.host_cloud else "device-resident",
                        "result": "host (D2H inside step)" if args.host_result else "device-resident",
                        "parallelism": f"row-block x{world}"},
         }

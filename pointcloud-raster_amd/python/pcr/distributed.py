@@ -62,34 +62,49 @@ def exchange_halos(planes, own, state_row0, halo, rank, world, blocks=None, grou
     rows_in_state = planes[0][0].shape[0]
     s1 = state_row0 + rows_in_state
     ops, recvs = [], []
+    # gloo cannot move device tensors point-to-point: stage through host memory (rehearsals and
+    # tests only; the production backend is nccl = RCCL, which sends from HBM over xGMI)
+    stage = dist.get_backend(group) == "gloo" and planes[0][0].is_cuda
+
+    def outgoing(t):
+        return t.cpu().contiguous() if stage else t.contiguous()
+
+    def incoming(n, t):
+        return torch.empty((n, t.shape[1]), dtype=t.dtype, device="cpu" if stage else t.device)
+
     for t, kind in planes:
         # apron above my block belongs to rank-1; apron below to rank+1
         up_n = r0 - state_row0          # rows I hold above my block
         dn_n = s1 - r1                  # rows I hold below my block
         if rank > 0:
             if up_n > 0:
-                ops.append(dist.P2POp(dist.isend, t[:up_n].contiguous(), rank - 1, group))
+                ops.append(dist.P2POp(dist.isend, outgoing(t[:up_n]), rank - 1, group))
             # rank-1 holds min(halo, rows I own) of my top rows
             n = min(halo, r1 - r0)
-            buf = torch.empty((n, t.shape[1]), dtype=t.dtype, device=t.device)
+            buf = incoming(n, t)
             ops.append(dist.P2POp(dist.irecv, buf, rank - 1, group))
             recvs.append((t[r0 - state_row0: r0 - state_row0 + n], buf, kind))
         if rank < world - 1:
             if dn_n > 0:
-                ops.append(dist.P2POp(dist.isend, t[rows_in_state - dn_n:].contiguous(), rank + 1, group))
+                ops.append(dist.P2POp(dist.isend, outgoing(t[rows_in_state - dn_n:]), rank + 1, group))
             n = min(halo, r1 - r0)
-            buf = torch.empty((n, t.shape[1]), dtype=t.dtype, device=t.device)
+            buf = incoming(n, t)
             ops.append(dist.P2POp(dist.irecv, buf, rank + 1, group))
             recvs.append((t[r1 - state_row0 - n: r1 - state_row0], buf, kind))
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     for dst, buf, kind in recvs:
-        _merge(dst, buf, kind)
+        _merge(dst, buf.to(dst.device) if stage else buf, kind)
 
 
 def allreduce_touched(touched, group=None):
     """A reference tile is 'touched' if any rank saw a valid point in it (int32 flags)."""
-    dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=group)
+    if dist.get_backend(group) == "gloo" and touched.is_cuda:
+        host = touched.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        touched.copy_(host)
+    else:
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=group)
 
 
 class ShardedPipeline:
