@@ -158,6 +158,13 @@ int pcr_hip_plane_merge(uint32_t plane_kind, float* d_dst, const float* d_src, i
 int pcr_hip_finalize(int rtype, const pcr_hip_grid* g, const pcr_hip_planes* planes,
                      const uint32_t* d_tile_touched, float* d_out, pcr_hip_stream s);
 
+/* Same, for up to PCR_HIP_MAX_FINALIZE_OUTPUTS reductions that read ONE group's planes: each plane is
+ * read once and every band written once (Sum + Count + Average of one channel: 2 plane reads, 3 band
+ * writes instead of 4 + 3). */
+#define PCR_HIP_MAX_FINALIZE_OUTPUTS 8
+int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
+                           int n_out, const int* rtypes, float* const* d_outs, pcr_hip_stream s);
+
 /* ---- scatter engine.  replaces: TileRouter::assign + sort + extract_batches
  *      (include/pcr/engine/tile_router_kernels.h:15-52, src/engine/tile_router.cpp:51-366),
  *      Accumulator::accumulate (include/pcr/engine/accumulator_kernels.h:13-23,

@@ -67,7 +67,7 @@ struct BinBuffers {                     // device pointers into the engine's scr
     const unsigned* n_items;
     int max_items;
 };
-constexpr int kMaxBins = 4096;
+constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 12 B per bin <= 160 KB
 constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
 
 // Passes A (histogram + routing keys), scan, B (LDS-staged scatter).  index_records: record.y is

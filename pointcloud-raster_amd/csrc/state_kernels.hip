@@ -115,6 +115,70 @@ k_finalize(GridDev g, const float* __restrict__ pa, const float* __restrict__ pb
     }
 }
 
+// Several reductions over one group's planes in one sweep.
+struct FinalizeOuts {
+    int n;
+    int rtype[PCR_HIP_MAX_FINALIZE_OUTPUTS];
+    float* out[PCR_HIP_MAX_FINALIZE_OUTPUTS];
+};
+
+__device__ __forceinline__ float finalize_rt(int rt, float s, float w, float mx, float mn) {
+    switch (rt) {
+        case PCR_HIP_SUM: return s;
+        case PCR_HIP_COUNT: return w > 0.0f ? w : NAN;
+        case PCR_HIP_MAX: return mx == -FLT_MAX ? NAN : mx;
+        case PCR_HIP_MIN: return mn == FLT_MAX ? NAN : mn;
+        default: return w > 0.0f ? s / w : NAN;
+    }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_finalize_group(GridDev g, PlanesDev pl, unsigned need, const uint32_t* __restrict__ touched, FinalizeOuts fo) {
+    const int rows = g.own_r1 - g.own_r0;
+    const int per_row = g.W / VEC;
+    const int64_t items = (int64_t)rows * per_row;
+    const bool one_tile = (g.tiles_x * g.tiles_y == 1);
+    const bool all_touched = (touched == nullptr) || (one_tile && touched[0] != 0u);
+    const bool none_touched = (touched != nullptr) && one_tile && touched[0] == 0u;
+    for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < items; it += (int64_t)gridDim.x * kBlock) {
+        int r = (int)(it / per_row);
+        int c = (int)(it - (int64_t)r * per_row) * VEC;
+        int row = g.own_r0 + r;
+        int64_t si = (int64_t)(row - g.st_r0) * g.W + c;
+        int64_t oi = (int64_t)r * g.W + c;
+        float s[VEC], w[VEC], mx[VEC], mn[VEC];
+        bool live[VEC];
+        if (VEC == 4) {
+            float4 t;
+            if (need & 1) { t = *reinterpret_cast<const float4*>(pl.sum + si); s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w; }
+            if (need & 2) { t = *reinterpret_cast<const float4*>(pl.wgt + si); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
+            if (need & 4) { t = *reinterpret_cast<const float4*>(pl.mx + si); mx[0] = t.x; mx[1] = t.y; mx[2] = t.z; mx[3] = t.w; }
+            if (need & 8) { t = *reinterpret_cast<const float4*>(pl.mn + si); mn[0] = t.x; mn[1] = t.y; mn[2] = t.z; mn[3] = t.w; }
+        } else {
+            if (need & 1) s[0] = pl.sum[si];
+            if (need & 2) w[0] = pl.wgt[si];
+            if (need & 4) mx[0] = pl.mx[si];
+            if (need & 8) mn[0] = pl.mn[si];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (!(need & 1)) s[k] = 0.f;
+            if (!(need & 2)) w[k] = 0.f;
+            if (!(need & 4)) mx[k] = -FLT_MAX;
+            if (!(need & 8)) mn[k] = FLT_MAX;
+            live[k] = all_touched || (!none_touched && touched[(row / g.th) * g.tiles_x + (c + k) / g.tw] != 0u);
+        }
+        for (int o = 0; o < fo.n; ++o) {
+            float v[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) v[k] = live[k] ? finalize_rt(fo.rtype[o], s[k], w[k], mx[k], mn[k]) : NAN;
+            if (VEC == 4) *reinterpret_cast<float4*>(fo.out[o] + oi) = make_float4(v[0], v[1], v[2], v[3]);
+            else fo.out[o][oi] = v[0];
+        }
+    }
+}
+
 template <int RT>
 int launch_finalize(const GridDev& g, const float* pa, const float* pb, const uint32_t* touched,
                     float* out, hipStream_t s) {
@@ -200,6 +264,51 @@ int pcr_hip_plane_merge(uint32_t plane_kind, float* d_dst, const float* d_src, i
         default: return fail(PCR_HIP_INVALID_ARGUMENT, "plane_merge: exactly one PCR_HIP_PLANE_* kind expected");
     }
     return merge_kind(kind, d_dst, d_src, cells, static_cast<hipStream_t>(s));
+}
+
+int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
+                           int n_out, const int* rtypes, float* const* d_outs, pcr_hip_stream s) {
+    int rc = validate_grid(g);
+    if (rc) return rc;
+    PCR_REQUIRE(planes && rtypes && d_outs, "finalize_group: null argument");
+    PCR_REQUIRE(n_out >= 1 && n_out <= PCR_HIP_MAX_FINALIZE_OUTPUTS, "finalize_group: 1..8 outputs");
+    GridDev gd = make_grid_dev(*g);
+    const int rows = gd.own_r1 - gd.own_r0;
+    if (rows <= 0) return PCR_HIP_OK;
+    FinalizeOuts fo;
+    fo.n = n_out;
+    unsigned need = 0;
+    bool aligned = gd.W % 4 == 0;
+    for (int i = 0; i < n_out; ++i) {
+        fo.rtype[i] = rtypes[i];
+        fo.out[i] = d_outs[i];
+        PCR_REQUIRE(d_outs[i], "finalize_group: null output band");
+        aligned = aligned && (reinterpret_cast<uintptr_t>(d_outs[i]) & 15) == 0;
+        switch (rtypes[i]) {
+            case PCR_HIP_SUM: need |= 1; break;
+            case PCR_HIP_COUNT: need |= 2; break;
+            case PCR_HIP_MAX: need |= 4; break;
+            case PCR_HIP_MIN: need |= 8; break;
+            case PCR_HIP_AVERAGE: case PCR_HIP_WEIGHTED_AVERAGE: need |= 3; break;
+            default: return fail(PCR_HIP_INVALID_ARGUMENT, "pipeline: unknown reduction type");
+        }
+    }
+    PCR_REQUIRE(!(need & 1) || planes->d_sum, "finalize_group: sum plane missing");
+    PCR_REQUIRE(!(need & 2) || planes->d_wgt, "finalize_group: weight plane missing");
+    PCR_REQUIRE(!(need & 4) || planes->d_max, "finalize_group: max plane missing");
+    PCR_REQUIRE(!(need & 8) || planes->d_min, "finalize_group: min plane missing");
+    PlanesDev pl{planes->d_sum, planes->d_wgt, planes->d_max, planes->d_min};
+    for (float* p : {pl.sum, pl.wgt, pl.mx, pl.mn}) aligned = aligned && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    hipStream_t st = static_cast<hipStream_t>(s);
+    if (aligned) {
+        hipLaunchKernelGGL(k_finalize_group<4>, dim3(grid_for((int64_t)rows * (gd.W / 4))), dim3(kBlock), 0, st,
+                           gd, pl, need, d_tile_touched, fo);
+    } else {
+        hipLaunchKernelGGL(k_finalize_group<1>, dim3(grid_for((int64_t)rows * gd.W)), dim3(kBlock), 0, st,
+                           gd, pl, need, d_tile_touched, fo);
+    }
+    PCR_HIP_TRY(hipGetLastError());
+    return PCR_HIP_OK;
 }
 
 int pcr_hip_finalize(int rtype, const pcr_hip_grid* g, const pcr_hip_planes* planes,

@@ -349,15 +349,33 @@ struct Pipeline::Impl {
         uint32_t* d_touched = nullptr;
         Status s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, nullptr, nullptr));
         if (!s.ok()) return s;
-        for (size_t r = 0; r < outputs.size(); ++r) {
-            float* dst = on_device ? result->band_f32((int)r) : static_cast<float*>(d_bands[r].data());
-            s = detail::hip_status(pcr_hip_finalize(static_cast<int>(outputs[r].type), &hg,
-                                                    &groups[outputs[r].group].view, d_touched, dst, stream));
-            if (!s.ok()) return s;
+        // one sweep per accumulation group: its planes are read once for all of its bands
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            std::vector<int> types;
+            std::vector<float*> dsts;
+            std::vector<size_t> bands_of;
+            auto flush = [&]() -> Status {
+                if (types.empty()) return Status::success();
+                Status fs = detail::hip_status(pcr_hip_finalize_group(&hg, &groups[gi].view, d_touched, (int)types.size(),
+                                                                      types.data(), dsts.data(), stream));
+                types.clear();
+                dsts.clear();
+                return fs;
+            };
+            for (size_t r = 0; r < outputs.size(); ++r) {
+                if (outputs[r].group != (int)gi) continue;
+                types.push_back(static_cast<int>(outputs[r].type));
+                dsts.push_back(on_device ? result->band_f32((int)r) : static_cast<float*>(d_bands[r].data()));
+                bands_of.push_back(r);
+                if (types.size() == PCR_HIP_MAX_FINALIZE_OUTPUTS && !(s = flush()).ok()) return s;
+            }
+            if (!(s = flush()).ok()) return s;
             if (!on_device) {
-                s = detail::hip_status(pcr_hip_memcpy_d2h(result->band_f32((int)r), dst,
-                                                          (size_t)rows * W * sizeof(float), stream));
-                if (!s.ok()) return s;
+                for (size_t r : bands_of) {
+                    s = detail::hip_status(pcr_hip_memcpy_d2h(result->band_f32((int)r), d_bands[r].data(),
+                                                              (size_t)rows * W * sizeof(float), stream));
+                    if (!s.ok()) return s;
+                }
             }
         }
         s = detail::hip_status(pcr_hip_stream_synchronize(stream));

@@ -87,6 +87,7 @@ SYMBOLS = {
     "pcr_hip_state_merge": [C.c_int, _VP, _VP, _I64, _VP],
     "pcr_hip_plane_merge": [_U32, _VP, _VP, _I64, _VP],
     "pcr_hip_finalize": [C.c_int, C.POINTER(Grid), C.POINTER(Planes), _VP, _VP, _VP],
+    "pcr_hip_finalize_group": [C.POINTER(Grid), C.POINTER(Planes), _VP, C.c_int, C.POINTER(C.c_int), C.POINTER(_VP), _VP],
     "pcr_hip_engine_create": [C.POINTER(_VP), C.POINTER(Grid), _SZ, _VP],
     "pcr_hip_engine_destroy": [_VP],
     "pcr_hip_engine_set_path": [_VP, C.c_int],
