@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--points", type=int, default=50_000_000, help="points per GPU")
     ap.add_argument("--grid", type=int, default=4096, help="grid width = rows per GPU")
-    ap.add_argument("--path", default="auto", choices=["auto", "direct", "binned"])
+    ap.add_argument("--path", default="auto", choices=["auto", "direct", "binned", "moments"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="points of the CPU baseline sample (0 = skip)")
     ap.add_argument("--host-result", action="store_true", help="finalize into host memory (PCIe-inclusive)")
     ap.add_argument("--host-cloud", action="store_true", help="ingest a host-resident cloud (PCIe-inclusive)")
@@ -160,7 +160,7 @@ def main():
     cfg.cuda_device_id = local_rank
     cfg.reductions = make_specs(args.workload)
     cfg.result_location = pcr.MemoryLocation.Host if args.host_result else pcr.MemoryLocation.Device
-    cfg.scatter_path = {"auto": 0, "direct": 1, "binned": 2}[args.path]
+    cfg.scatter_path = {"auto": 0, "direct": 1, "binned": 2, "moments": 3}[args.path]
 
     # this rank's rows [rank*G, (rank+1)*G) <=> world y in (H - (rank+1)*G, H - rank*G)
     y_hi = float(H - rank * G)

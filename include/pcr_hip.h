@@ -98,7 +98,7 @@ typedef struct pcr_hip_glyph {
 typedef struct pcr_hip_scatter_stats {
     uint64_t points_in;        /* points offered */
     uint64_t points_valid;     /* inside bounds and inside [own_row0, own_row1) */
-    int32_t path;              /* 0 = direct global atomics, 1 = binned LDS tiles */
+    int32_t path;              /* 0 = direct global atomics, 1 = binned LDS tiles, 2 = moments + convolution */
     int32_t lds_tile_w, lds_tile_h, lds_apron, num_bins;
 } pcr_hip_scatter_stats;
 
@@ -174,7 +174,8 @@ typedef struct pcr_hip_engine pcr_hip_engine;
 /* scratch_bytes = 0: the engine grows its scratch arena on demand. */
 int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s);
 int pcr_hip_engine_destroy(pcr_hip_engine* e);
-/* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot be binned) */
+/* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot
+ * be binned), 3 = force the separable moment + convolution path for Gaussians (other glyphs: as auto) */
 int pcr_hip_engine_set_path(pcr_hip_engine* e, int path);
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
 /* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */

@@ -99,7 +99,8 @@ int pcr_hip_engine_destroy(pcr_hip_engine* e) {
 
 int pcr_hip_engine_set_path(pcr_hip_engine* e, int path) {
     PCR_REQUIRE(e, "engine_set_path: null engine");
-    PCR_REQUIRE(path >= 0 && path <= 2, "engine_set_path: path must be 0 (auto), 1 (direct) or 2 (binned)");
+    PCR_REQUIRE(path >= 0 && path <= 3,
+                "engine_set_path: path must be 0 (auto), 1 (direct), 2 (binned) or 3 (moments, Gaussian only)");
     e->forced_path = path;
     return PCR_HIP_OK;
 }
@@ -170,6 +171,7 @@ int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_
     rc = begin_scatter(e, n);
     if (rc) return rc;
     bool can_bin = binned_point_supported(e, plane_mask);
+    if (e->forced_path == 3 && can_bin) return binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: binned path forced but not applicable to this grid");
     if (e->forced_path == 2 || (e->forced_path == 0 && can_bin))
@@ -209,6 +211,12 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     gl.rotation = glyph->d_rotation;
     rc = begin_scatter(e, n);
     if (rc) return rc;
+    if (e->forced_path == 3 || e->forced_path == 0) {
+        bool can_mom = moments_supported(e, gl, plane_mask);
+        if (e->forced_path == 3 && !can_mom && gl.type == PCR_HIP_GLYPH_GAUSSIAN)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path forced but not applicable to this glyph");
+        if (can_mom) return moments_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    }
     bool can_bin = binned_glyph_supported(e, gl, plane_mask);
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: binned path forced but not applicable");

@@ -17,7 +17,7 @@ struct pcr_hip_engine {
     int ntiles = 0;
     unsigned long long* d_counters = nullptr;  // [0] = valid points of the last scatter
 
-    int forced_path = 0;                       // 0 auto, 1 direct, 2 binned
+    int forced_path = 0;                       // 0 auto, 1 direct, 2 binned, 3 moments (Gaussian only)
     pcr_hip_scatter_stats stats{};
 
     // optional per-kernel event timing
@@ -90,5 +90,10 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
 bool binned_glyph_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);
 int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n);
+
+// separable moment + convolution path for large default-sigma Gaussians, scatter_moments.hip
+bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);
+int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
+                  const double* x, const double* y, const float* v, uint64_t n);
 
 }  // namespace pcrhip

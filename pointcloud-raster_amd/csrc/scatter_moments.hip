@@ -1,0 +1,633 @@
+// scatter_moments.hip -- large-sigma Gaussian glyphs without per-cell scatter.
+//
+// A default-sigma, unrotated Gaussian footprint is separable, and its dependence on the point's
+// sub-cell offset s (s' = s - 1/2 in [-1/2, 1/2)) can be expanded exactly enough:
+//
+//   exp(-(d - s)^2 / 2 sigma^2) = exp(-u^2/2 sigma^2) * exp(u s'/sigma^2) * exp(-s'^2/2 sigma^2),   u = d - 1/2
+//                               = sum_k A_k(d) m_k(s'),   A_k(d) = exp(-u^2/2 sigma^2) (u/sigma^2)^k / k!,
+//                                                         m_k(s') = s'^k exp(-s'^2/2 sigma^2)
+//
+// |u s'/sigma^2| <= (r + 1/2)/(2 sigma^2) is small for large sigma, so a total order K of 5 (sigma=16)
+// to 9 (sigma=4) reproduces the reference weights to ~1e-7 (tests, numpy prototype).  Then
+//
+//   splat = sum_{k+l<=K} (A_k (x) B_l) * M_kl ,   M_kl[cell] = sum_{points centred in cell} v m_k(s'x) n_l(s'y)
+//
+// i.e. (1) ONE Point-style pass builds P = (K+1)(K+2)/2 moment planes per plane kind -- points are
+// binned by tile, sorted by cell inside LDS, and reduced per cell in registers, no atomics on the
+// moments at all -- and (2) separable (2r+1)-tap convolutions, independent of the number of points,
+// spread them: column pass U_k = sum_l B_l * M_kl, row pass out += sum_k A_k * U_k.  The footprint
+// window |d| <= r is the convolution support; clipping to the reference tile of the centre cell (Q4)
+// becomes "taps never cross a reference-tile edge".  The 1e-6 weight cut-off of the reference is
+// provably dead for these parameters (checked on the host), otherwise the path is not taken.
+//
+// Work per point drops from (2r+1)^2 weighted atomics (9409 at sigma=16) to ~P multiply-adds.
+// Points the expansion cannot represent (non-finite value, centre cell not the routed cell at a
+// grid edge) are painted by the wave-per-point direct kernel afterwards.
+#include "engine.hpp"
+#include "glyph_device.hpp"
+
+#include <vector>
+
+using namespace pcrhip;
+
+namespace {
+
+constexpr int kThreads = 1024;        // count / scatter passes
+constexpr int kMomThreads = 512;      // per-tile moment reduction (register heavy)
+constexpr int kPad = 16;              // zero padding of the tap tables (16-output sliding windows)
+constexpr int kTileW = 128, kTileH = 72;                 // 9216 cells: two u32 tables + index list fit the LDS
+constexpr int kTileCells = kTileW * kTileH;
+constexpr int kSortChunk = 20480;                        // records sorted per round inside LDS
+constexpr int kMaxK = 9;
+
+struct MomPlan {
+    BinGeom bins;
+    int K, P, r;
+    float inv2sx2, inv2sy2;           // 1 / (2 sigma^2), cells^-2
+    float inv_csx_f, inv_csy_f;
+};
+
+__device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u; }
+
+// ---- pass A: eligibility + histogram -----------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
+            const float* __restrict__ v, uint64_t n, unsigned* __restrict__ keys,
+            unsigned* __restrict__ bin_count, unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count,
+            uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
+    extern __shared__ unsigned lds_hist[];
+    for (int i = threadIdx.x; i < b.nbins; i += kThreads) lds_hist[i] = 0;
+    __shared__ unsigned any_valid;
+    if (threadIdx.x == 0) any_valid = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
+    unsigned my_valid = 0;
+    for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
+        uint64_t i = base + k;
+        if (i >= n) break;
+        double wx = x[i], wy = y[i];
+        PointGeom pg = point_geom(g, wx, wy);
+        unsigned key = 0xFFFFFFFFu;
+        if (pg.valid) {
+            ++my_valid;
+            touch_tile(g, touched, pg.row, pg.col);
+            int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);
+            if (finite_f(v[i]) && icx == pg.col && icy == pg.row) {
+                int sr = pg.row - g.st_r0;
+                int bx = pg.col / b.tile_w, by = sr / b.tile_h;
+                int bin = by * b.bins_x + bx;
+                key = ((unsigned)bin << kLcellBits) | (unsigned)((sr - by * b.tile_h) * b.tile_w + (pg.col - bx * b.tile_w));
+                atomicAdd(&lds_hist[bin], 1u);
+            } else {
+                fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;           // rare: painted directly afterwards
+            }
+        }
+        keys[i] = key;
+    }
+    if (my_valid) atomicAdd(&any_valid, my_valid);
+    __syncthreads();
+    for (int i = threadIdx.x; i < b.nbins; i += kThreads) {
+        unsigned c = lds_hist[i];
+        if (c) atomicAdd(&bin_count[i], c);
+    }
+    if (threadIdx.x == 0 && any_valid) atomicAdd(counters, (unsigned long long)any_valid);
+}
+
+// bin starts (no work items: one workgroup per bin, empty bins included so that every moment
+// cell is written and no memset of the planes is needed)
+__global__ void __launch_bounds__(kThreads)
+k_mom_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restrict__ bin_start,
+           unsigned* __restrict__ cursor) {
+    __shared__ unsigned part[kThreads];
+    const int per = (nbins + kThreads - 1) / kThreads;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
+    unsigned s = 0;
+    for (int i = lo; i < hi; ++i) s += bin_count[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+        unsigned a = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += a;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) {
+        bin_start[i] = run;
+        cursor[i] = run;
+        run += bin_count[i];
+    }
+    if (threadIdx.x == kThreads - 1) bin_start[nbins] = part[threadIdx.x];
+}
+
+// ---- pass B: 16-byte records {local cell, value, s'x, s'y}, grouped by bin ---------------------------
+constexpr int kScatterPer = 8;         // 8192-point chunks: 128 KB of staging
+
+__global__ void __launch_bounds__(kThreads)
+k_mom_scatter(GridDev g, BinGeom b, const unsigned* __restrict__ keys, const double* __restrict__ x,
+              const double* __restrict__ y, const float* __restrict__ v, uint64_t n,
+              unsigned* __restrict__ cursor, uint4* __restrict__ records) {
+    extern __shared__ unsigned char lds_raw[];
+    uint4* stage = reinterpret_cast<uint4*>(lds_raw);
+    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)b.chunk * sizeof(uint4));
+    unsigned* loff = hist + b.nbins;
+    unsigned* gbase = loff + b.nbins;
+    __shared__ unsigned wave_tot[kThreads / 64];
+    for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
+    __syncthreads();
+
+    const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
+    unsigned key[kScatterPer], rank[kScatterPer];
+    float val[kScatterPer], sx[kScatterPer], sy[kScatterPer];
+#pragma unroll
+    for (int k = 0; k < kScatterPer; ++k) {
+        uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+        key[k] = i < n ? keys[i] : 0xFFFFFFFFu;
+        rank[k] = 0;
+        val[k] = sx[k] = sy[k] = 0.f;
+        if (key[k] != 0xFFFFFFFFu) {
+            double fcx = (x[i] - g.min_x) * g.inv_csx, fcy = (y[i] - g.max_y) * g.inv_csy;
+            sx[k] = (float)(fcx - floor(fcx)) - 0.5f;        // the reference's f32 sub-cell offset, recentred
+            sy[k] = (float)(fcy - floor(fcy)) - 0.5f;
+            val[k] = v[i];
+            rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
+        }
+    }
+    __syncthreads();
+    const int per = (b.nbins + kThreads - 1) / kThreads;
+    const int lo = threadIdx.x * per, hi = min(lo + per, b.nbins);
+    unsigned s = 0;
+    for (int i = lo; i < hi; ++i) s += hist[i];
+    unsigned incl = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+    unsigned run = wave_base + incl - s;
+    for (int i = lo; i < hi; ++i) {
+        unsigned c = hist[i];
+        loff[i] = run;
+        if (c) gbase[i] = atomicAdd(&cursor[i], c);
+        run += c;
+    }
+    unsigned total = 0;
+    for (int w = 0; w < kThreads / 64; ++w) total += wave_tot[w];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kScatterPer; ++k)
+        if (key[k] != 0xFFFFFFFFu)
+            stage[loff[key[k] >> kLcellBits] + rank[k]] =
+                make_uint4(key[k], __float_as_uint(val[k]), __float_as_uint(sx[k]), __float_as_uint(sy[k]));
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < total; j += kThreads) {
+        uint4 rec = stage[j];
+        unsigned bin = rec.x >> kLcellBits;
+        rec.x &= (1u << kLcellBits) - 1;
+        records[gbase[bin] + (j - loff[bin])] = rec;
+    }
+}
+
+// ---- pass C: per-tile moments: sort the bin's records by cell in LDS, reduce per cell in registers ----
+template <int K, unsigned MASK>
+__global__ void __launch_bounds__(kMomThreads)
+k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* __restrict__ records,
+               const unsigned* __restrict__ bin_start, float* __restrict__ mom_v, float* __restrict__ mom_w,
+               int64_t plane_stride) {
+    constexpr int P = (K + 1) * (K + 2) / 2;
+    extern __shared__ unsigned lds_u[];
+    unsigned* off = lds_u;                         // [kTileCells + 1]
+    unsigned* cur = off + kTileCells + 1;          // [kTileCells]
+    unsigned* idx = cur + kTileCells;              // [kSortChunk]
+    __shared__ unsigned wave_tot[kMomThreads / 64];
+
+    const int bin = blockIdx.x;
+    const unsigned first = bin_start[bin], count = bin_start[bin + 1] - first;
+    const int bx = bin % b.bins_x, by = bin / b.bins_x;
+    const int c0 = bx * kTileW, r0 = by * kTileH;
+    const int w = min(kTileW, g.W - c0), h = min(kTileH, g.st_rows - r0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kPer = kTileCells / kMomThreads;           // 18 cells per thread in the scan
+
+    for (unsigned cbase = 0; cbase == 0 || cbase < count; cbase += kSortChunk) {
+        const unsigned cn = min((unsigned)kSortChunk, count - cbase);
+        const uint4* rec = records + first + cbase;
+        for (int i = threadIdx.x; i < kTileCells; i += kMomThreads) cur[i] = 0;
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < cn; j += kMomThreads) atomicAdd(&cur[rec[j].x], 1u);
+        __syncthreads();
+        // exclusive scan of cur -> off (thread t owns cells [t*kPer, (t+1)*kPer))
+        unsigned s = 0;
+        for (int i = 0; i < kPer; ++i) s += cur[threadIdx.x * kPer + i];
+        unsigned incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - s;
+        for (int wv = 0; wv < wave; ++wv) run += wave_tot[wv];
+        for (int i = 0; i < kPer; ++i) {
+            int c = threadIdx.x * kPer + i;
+            unsigned cc = cur[c];
+            off[c] = run;
+            run += cc;
+        }
+        if (threadIdx.x == kMomThreads - 1) off[kTileCells] = run;
+        __syncthreads();
+        for (int i = threadIdx.x; i < kTileCells; i += kMomThreads) cur[i] = off[i];
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < cn; j += kMomThreads) idx[atomicAdd(&cur[rec[j].x], 1u)] = j;
+        __syncthreads();
+
+        // per cell: fold its records into P (x2) moments held in registers, write the planes
+        for (int cell = threadIdx.x; cell < kTileCells; cell += kMomThreads) {
+            const int ly = cell / kTileW, lx = cell - ly * kTileW;
+            if (lx >= w || ly >= h) continue;
+            float av[P], aw[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) { av[p] = 0.f; aw[p] = 0.f; }
+            const unsigned e0 = off[cell], e1 = off[cell + 1];
+            for (unsigned e = e0; e < e1; ++e) {
+                const uint4 rc = rec[idx[e]];
+                const float val = __uint_as_float(rc.y), sx = __uint_as_float(rc.z), sy = __uint_as_float(rc.w);
+                float mx[K + 1], ny[K + 1];
+                mx[0] = expf(-(sx * sx) * inv2sx2);
+                ny[0] = expf(-(sy * sy) * inv2sy2);
+#pragma unroll
+                for (int k = 1; k <= K; ++k) { mx[k] = mx[k - 1] * sx; ny[k] = ny[k - 1] * sy; }
+                int p = 0;
+#pragma unroll
+                for (int k = 0; k <= K; ++k) {
+#pragma unroll
+                    for (int l = 0; l <= K - k; ++l) {
+                        const float m = mx[k] * ny[l];
+                        if (MASK & 1) av[p] += val * m;
+                        if (MASK & 2) aw[p] += m;
+                        ++p;
+                    }
+                }
+            }
+            const int64_t gcell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
+            if (cbase == 0) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (MASK & 1) mom_v[p * plane_stride + gcell] = av[p];
+                    if (MASK & 2) mom_w[p * plane_stride + gcell] = aw[p];
+                }
+            } else if (e1 > e0) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (MASK & 1) mom_v[p * plane_stride + gcell] += av[p];
+                    if (MASK & 2) mom_w[p * plane_stride + gcell] += aw[p];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- convolutions ---------------------------------------------------------------------------------------
+// Column pass: U_k[y][x] = sum_{l <= K-k} sum_dy B_l(dy) M_kl[y - dy][x]; sources stay inside the output
+// row's reference tile and the state window.  One lane per column, 16 consecutive output rows per
+// wave in registers, taps as wave-uniform (scalar) loads from the zero-padded tables.
+__global__ void __launch_bounds__(256)
+k_conv_col(GridDev g, int K, int r, int yblocks_per_tile, const float* __restrict__ taps_y,
+           const float* __restrict__ mom, int64_t plane_stride, float* __restrict__ u_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int k = blockIdx.z;
+    const int trow = blockIdx.y / yblocks_per_tile, yb = blockIdx.y - trow * yblocks_per_tile;
+    // reference tile rows, in window coordinates
+    const int t_lo = max(trow * g.th - g.st_r0, 0), t_hi = min(min((trow + 1) * g.th, g.H) - g.st_r0, g.st_rows);
+    const int y0 = t_lo + yb * 64 + wave * 16;
+    if (y0 >= t_hi) return;
+    const int tap_w = 2 * r + 1 + 2 * kPad;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    // pair index of (k, 0): sum_{i<k} (K + 1 - i)
+    int p0 = 0;
+    for (int i = 0; i < k; ++i) p0 += K + 1 - i;
+    const int yi_lo = max(y0 - r, t_lo), yi_hi = min(y0 + 15 + r, t_hi - 1);
+    const bool xin = x < g.W;
+    for (int l = 0; l <= K - k; ++l) {
+        const float* plane = mom + (int64_t)(p0 + l) * plane_stride;
+        const float* tl = taps_y + l * tap_w;
+        for (int yi = yi_lo; yi <= yi_hi; ++yi) {
+            const float val = xin ? plane[(int64_t)yi * g.W + x] : 0.f;
+            const float* tw = tl + (y0 - yi + r + kPad);            // dy = (y0 + j) - yi  -> index dy + r (+pad)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * val;
+        }
+    }
+    if (!xin) return;
+    float* uo = u_out + (int64_t)k * plane_stride;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (y0 + j < t_hi) uo[(int64_t)(y0 + j) * g.W + x] = acc[j];
+}
+
+// Row pass + accumulate: out[y][x] += sum_k sum_dx A_k(dx) U_k[y][x - dx], sources inside the output
+// column's reference tile.  The U_k tile goes through LDS (odd row stride) so that one lane owns one
+// row and slides 16 outputs along x; results return through LDS for a coalesced read-modify-write.
+__global__ void __launch_bounds__(256)
+k_conv_row_accum(GridDev g, int K, int r, int xblocks_per_tile, const float* __restrict__ taps_x,
+                 const float* __restrict__ u_in, int64_t plane_stride, float* __restrict__ out_plane) {
+    extern __shared__ float lds_f[];
+    const int tcol = blockIdx.x / xblocks_per_tile, xb = blockIdx.x - tcol * xblocks_per_tile;
+    const int t_lo = tcol * g.tw, t_hi = min((tcol + 1) * g.tw, g.W);
+    const int bx0 = t_lo + xb * 64;
+    if (bx0 >= t_hi) return;
+    const int by0 = blockIdx.y * 64;
+    const int span = 64 + 2 * r;                       // source columns [bx0 - r, bx0 + 64 + r)
+    const int stride = span | 1;                       // odd: lanes (rows) hit different banks
+    float* tile = lds_f;                               // [64][stride]
+    float* outt = lds_f + 64 * stride;                 // [64][65]
+    const int row = threadIdx.x & 63, xq = threadIdx.x >> 6;
+    const int x0 = bx0 + xq * 16;
+    const int tap_w = 2 * r + 1 + 2 * kPad;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int xi_lo = max(x0 - r, t_lo), xi_hi = min(x0 + 15 + r, t_hi - 1);
+    for (int k = 0; k <= K; ++k) {
+        const float* uk = u_in + (int64_t)k * plane_stride;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * span; i += 256) {
+            int ry = i / span, cx = i - ry * span;
+            int gx = bx0 - r + cx, gy = by0 + ry;
+            float val = 0.f;
+            if (gx >= t_lo && gx < t_hi && gy < g.st_rows) val = uk[(int64_t)gy * g.W + gx];
+            tile[ry * stride + cx] = val;
+        }
+        __syncthreads();
+        const float* tk = taps_x + k * tap_w;
+        for (int xi = xi_lo; xi <= xi_hi; ++xi) {
+            const float val = tile[row * stride + (xi - (bx0 - r))];
+            const float* tw = tk + (x0 - xi + r + kPad);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * val;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) outt[row * 65 + xq * 16 + j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int ry = i >> 6, cx = i & 63;
+        int gx = bx0 + cx, gy = by0 + ry;
+        if (gx < t_hi && gy < g.st_rows) {
+            float a = outt[ry * 65 + cx];
+            if (a != 0.f) out_plane[(int64_t)gy * g.W + gx] += a;
+        }
+    }
+}
+
+// ---- fallback: wave-per-point direct splat of the listed points --------------------------------------
+template <unsigned MASK>
+struct DirectSink {
+    const GridDev& g;
+    PlanesDev pl;
+    __device__ __forceinline__ void add(int row, int col, float vw, float w) {
+        int64_t cell = (int64_t)(row - g.st_r0) * g.W + col;
+        if (MASK & 1) atomic_add_f32(pl.sum + cell, vw);
+        if (MASK & 2) atomic_add_f32(pl.wgt + cell, w);
+    }
+};
+
+template <unsigned MASK>
+__global__ void __launch_bounds__(256)
+k_gauss_list(GridDev g, GlyphDev gl, PlanesDev pl, const unsigned* __restrict__ list,
+             const unsigned* __restrict__ count, const double* __restrict__ x, const double* __restrict__ y,
+             const float* __restrict__ v) {
+    const unsigned n = *count;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    DirectSink<MASK> sink{g, pl};
+    for (unsigned base = wave * 64; base < n; base += nwaves * 64) {
+        unsigned j = base + lane;
+        bool valid = j < n;
+        GaussParams q{};
+        if (valid) {
+            uint64_t i = list[j];
+            PointGeom pg = point_geom(g, x[i], y[i]);
+            valid = pg.valid;
+            if (valid) q = gauss_params(g, gl, pg, v[i], i);
+        }
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            GaussParams u = lane_bcast(q, src);
+            gauss_splat_wave(u, lane, sink);
+        }
+    }
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// host: plan from the glyph spec; false when the expansion does not apply
+bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
+    if (gl.type != PCR_HIP_GLYPH_GAUSSIAN || gl.sigma_x || gl.sigma_y || gl.rotation) return false;
+    if (gl.def_rotation != 0.0f) return false;                       // cos == 1, sin == 0 exactly
+    const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
+    const float R = std::min(3.0f * std::max(sx, sy), gl.max_radius);
+    if (!(sx > 0.0f) || sy == 0.0f || !(R >= 1.0f) || R > 200.0f) return false;
+    const int r = (int)std::ceil(R);
+    const double asy = std::fabs((double)sy), sx2 = (double)sx * sx, sy2 = asy * asy;
+    // the reference drops weights < 1e-6 (glyph_kernels.cu:166): must never trigger inside the window
+    const double qmax = 0.5 * ((r + 1.0) * (r + 1.0) / sx2 + (r + 1.0) * (r + 1.0) / sy2);
+    if (qmax > 13.5) return false;
+    // total order K: remainder of exp(t), t = |u s'/sigma^2| summed over both axes
+    const double t = (r + 0.5) * 0.5 / sx2 + (r + 0.5) * 0.5 / sy2;
+    int K = 0;
+    double term = t;                                                   // t^(K+1)/(K+1)!
+    while (term > 1e-7 && K < 32) { ++K; term *= t / (K + 1); }
+    if (K > kMaxK) return false;
+    K = K <= 5 ? 5 : K <= 7 ? 7 : 9;                                   // instantiated orders
+    MomPlan p;
+    p.K = K;
+    p.P = (K + 1) * (K + 2) / 2;
+    p.r = r;
+    p.inv2sx2 = (float)(1.0 / (2.0 * sx2));
+    p.inv2sy2 = (float)(1.0 / (2.0 * sy2));
+    p.bins.tile_w = kTileW;
+    p.bins.tile_h = kTileH;
+    p.bins.bins_x = (g.W + kTileW - 1) / kTileW;
+    p.bins.bins_y = (g.st_rows + kTileH - 1) / kTileH;
+    p.bins.nbins = p.bins.bins_x * p.bins.bins_y;
+    p.bins.chunk = kScatterPer * kThreads;
+    if (p.bins.nbins > 2560) return false;                             // scatter staging: 128 KB + 12 B per bin
+    *out = p;
+    return true;
+}
+
+void fill_taps(std::vector<float>& t, int K, int r, double s2) {
+    const int tap_w = 2 * r + 1 + 2 * kPad;
+    t.assign((size_t)(K + 1) * tap_w, 0.0f);
+    for (int k = 0; k <= K; ++k) {
+        double fact = 1.0;
+        for (int i = 2; i <= k; ++i) fact *= i;
+        for (int d = -r; d <= r; ++d) {
+            double u = d - 0.5;
+            t[(size_t)k * tap_w + kPad + d + r] = (float)(std::exp(-u * u / (2.0 * s2)) * std::pow(u / s2, k) / fact);
+        }
+    }
+}
+
+template <int K, unsigned MASK>
+void launch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
+                    float* mom_v, float* mom_w, int64_t stride) {
+    const size_t lds = ((size_t)kTileCells * 2 + 1 + kSortChunk) * sizeof(unsigned);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_moments<K, MASK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_tile_moments<K, MASK>), dim3(p.bins.nbins), dim3(kMomThreads), lds, e->stream, e->gd,
+                       p.bins, p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
+}
+
+template <unsigned MASK>
+void dispatch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
+                      float* mom_v, float* mom_w, int64_t stride) {
+    if (p.K == 5) launch_moments<5, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 7) launch_moments<7, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+    else launch_moments<9, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+}
+
+}  // namespace
+
+namespace pcrhip {
+
+bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask) {
+    if (mask == 0 || (mask & ~3u)) return false;
+    MomPlan p;
+    if (!make_plan(e->gd, gl, &p)) return false;
+    if (e->stats.points_in >= (1ull << 32) - (1ull << 20)) return false;
+    if (e->forced_path == 3) return true;
+    // worth it when painting footprints costs more than the point-count independent convolutions:
+    // ~1.5 ps per footprint cell-update (measured, LDS-tile splat) vs ~0.12 ps per cell x pair x tap
+    const double splat = (double)e->stats.points_in * (2.0 * p.r + 1) * (2.0 * p.r + 1) * 1.5e-12;
+    const double conv = (double)e->gd.W * e->gd.st_rows * p.P * (2.0 * p.r + 1) * 2.0 * 0.12e-12 +
+                        (double)e->stats.points_in * (p.P * 0.04e-9 + 0.05e-9);
+    return p.r >= 6 && conv < splat;
+}
+
+int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
+                  const double* x, const double* y, const float* v, uint64_t n) {
+    MomPlan p;
+    if (!make_plan(e->gd, gl, &p)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path not applicable");
+    const GridDev& g = e->gd;
+    const BinGeom& b = p.bins;
+    const int64_t cells = (int64_t)g.W * g.st_rows;
+    const int kinds = ((mask & 1) ? 1 : 0) + ((mask & 2) ? 1 : 0);
+    const int tap_w = 2 * p.r + 1 + 2 * kPad;
+
+    size_t off = 0;
+    const size_t o_count = off;  off += align256((size_t)b.nbins * 4);
+    const size_t o_start = off;  off += align256((size_t)(b.nbins + 1) * 4);
+    const size_t o_cursor = off; off += align256((size_t)b.nbins * 4);
+    const size_t o_fbc = off;    off += 256;
+    const size_t o_taps = off;   off += align256((size_t)2 * (p.K + 1) * tap_w * 4);
+    const size_t o_keys = off;   off += align256((size_t)n * 4);
+    const size_t o_fbl = off;    off += align256((size_t)n * 4);
+    const size_t o_rec = off;    off += align256((size_t)n * 16);
+    const size_t o_mom = off;    off += align256((size_t)kinds * p.P * cells * 4);
+    const size_t o_u = off;      off += align256((size_t)(p.K + 1) * cells * 4);
+    int rc = ensure_scratch(e, off);
+    if (rc) return rc;
+    char* s = e->d_scratch;
+    unsigned* d_count = reinterpret_cast<unsigned*>(s + o_count);
+    unsigned* d_start = reinterpret_cast<unsigned*>(s + o_start);
+    unsigned* d_cursor = reinterpret_cast<unsigned*>(s + o_cursor);
+    unsigned* d_fbc = reinterpret_cast<unsigned*>(s + o_fbc);
+    float* d_taps = reinterpret_cast<float*>(s + o_taps);
+    unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
+    unsigned* d_fbl = reinterpret_cast<unsigned*>(s + o_fbl);
+    uint4* d_rec = reinterpret_cast<uint4*>(s + o_rec);
+    float* d_mom = reinterpret_cast<float*>(s + o_mom);
+    float* d_u = reinterpret_cast<float*>(s + o_u);
+    float* mom_v = (mask & 1) ? d_mom : nullptr;
+    float* mom_w = (mask & 2) ? d_mom + ((mask & 1) ? (int64_t)p.P * cells : 0) : nullptr;
+
+    // tap tables: x taps then y taps
+    const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
+    std::vector<float> tx, ty;
+    fill_taps(tx, p.K, p.r, (double)sx * sx);
+    fill_taps(ty, p.K, p.r, (double)sy * sy);
+    PCR_HIP_TRY(hipMemcpyAsync(d_taps, tx.data(), tx.size() * 4, hipMemcpyHostToDevice, e->stream));
+    PCR_HIP_TRY(hipMemcpyAsync(d_taps + tx.size(), ty.data(), ty.size() * 4, hipMemcpyHostToDevice, e->stream));
+    PCR_HIP_TRY(hipStreamSynchronize(e->stream));      // tx, ty are about to go out of scope
+    const float* taps_x = d_taps;
+    const float* taps_y = d_taps + tx.size();
+
+    PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
+    PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));
+    const int blocks = (int)((n + b.chunk - 1) / b.chunk);
+    {
+        ScopedKernelTimer t(e, "k_mom_count");
+        hipLaunchKernelGGL(k_mom_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream, g, b, x, y, v, n,
+                           d_keys, d_count, d_fbl, d_fbc, e->d_touched, e->d_counters);
+    }
+    {
+        ScopedKernelTimer t(e, "k_mom_scan");
+        hipLaunchKernelGGL(k_mom_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, d_count, d_start, d_cursor);
+    }
+    {
+        ScopedKernelTimer t(e, "k_mom_scatter");
+        const size_t lds = (size_t)b.chunk * 16 + (size_t)b.nbins * 12;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mom_scatter),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_mom_scatter, dim3(blocks), dim3(kThreads), lds, e->stream, g, b, d_keys, x, y, v, n,
+                           d_cursor, d_rec);
+    }
+    {
+        ScopedKernelTimer t(e, "k_tile_moments");
+        if (mask == 1) dispatch_moments<1>(e, p, d_rec, d_start, mom_v, mom_w, cells);
+        else if (mask == 2) dispatch_moments<2>(e, p, d_rec, d_start, mom_v, mom_w, cells);
+        else dispatch_moments<3>(e, p, d_rec, d_start, mom_v, mom_w, cells);
+    }
+    // convolutions, per plane kind
+    const int yblocks = (std::min(g.th, g.H) + 63) / 64, xblocks = (std::min(g.tw, g.W) + 63) / 64;
+    const int tiles_y = g.tiles_y, tiles_x = g.tiles_x;
+    const int span = 64 + 2 * p.r;
+    const size_t row_lds = ((size_t)64 * (span | 1) + 64 * 65) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_row_accum),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+    for (int kind = 0; kind < 2; ++kind) {
+        const float* mom = kind == 0 ? mom_v : mom_w;
+        float* outp = kind == 0 ? pl.sum : pl.wgt;
+        if (!mom) continue;
+        {
+            ScopedKernelTimer t(e, "k_conv_col");
+            hipLaunchKernelGGL(k_conv_col, dim3((g.W + 63) / 64, tiles_y * yblocks, p.K + 1), dim3(256), 0, e->stream,
+                               g, p.K, p.r, yblocks, taps_y, mom, cells, d_u);
+        }
+        {
+            ScopedKernelTimer t(e, "k_conv_row_accum");
+            hipLaunchKernelGGL(k_conv_row_accum, dim3(tiles_x * xblocks, (g.st_rows + 63) / 64), dim3(256), row_lds,
+                               e->stream, g, p.K, p.r, xblocks, taps_x, d_u, cells, outp);
+        }
+    }
+    {
+        ScopedKernelTimer t(e, "k_gauss_list");
+        const int fb_blocks = 64;                               // the list is normally empty; grid-strided
+        if (mask == 1) hipLaunchKernelGGL(k_gauss_list<1>, dim3(fb_blocks), dim3(256), 0, e->stream, g, gl, pl, d_fbl, d_fbc, x, y, v);
+        else if (mask == 2) hipLaunchKernelGGL(k_gauss_list<2>, dim3(fb_blocks), dim3(256), 0, e->stream, g, gl, pl, d_fbl, d_fbc, x, y, v);
+        else hipLaunchKernelGGL(k_gauss_list<3>, dim3(fb_blocks), dim3(256), 0, e->stream, g, gl, pl, d_fbl, d_fbc, x, y, v);
+    }
+    PCR_HIP_TRY(hipGetLastError());
+    e->stats.path = 2;
+    e->stats.lds_tile_w = kTileW;
+    e->stats.lds_tile_h = kTileH;
+    e->stats.lds_apron = p.K;           // reported: expansion order
+    e->stats.num_bins = b.nbins;
+    return PCR_HIP_OK;
+}
+
+}  // namespace pcrhip

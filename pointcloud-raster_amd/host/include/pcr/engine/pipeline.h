@@ -68,7 +68,7 @@ struct PipelineConfig {
     // is in [shard_row_begin, shard_row_end) and finalizes those rows; -1 = whole grid.
     int shard_row_begin = -1;
     int shard_row_end = -1;
-    int scatter_path = 0;                            // 0 auto, 1 direct atomics, 2 binned LDS tiles
+    int scatter_path = 0;                            // 0 auto, 1 direct atomics, 2 binned LDS tiles, 3 moments+convolution (Gaussian)
 };
 
 struct ProgressInfo {

@@ -145,7 +145,7 @@ void bind_engine(py::module_& m) {
         .def("last_scatter", [](const Pipeline& p) {
             auto s = p.last_scatter();
             py::dict d;
-            d["path"] = s.path == 1 ? "binned" : "direct";
+            d["path"] = s.path == 2 ? "moments" : s.path == 1 ? "binned" : "direct";
             d["lds_tile"] = py::make_tuple(s.lds_tile_w, s.lds_tile_h);
             d["lds_apron"] = s.lds_apron;
             d["num_bins"] = s.num_bins;

@@ -1,0 +1,147 @@
+"""The separable moment + convolution path for large default-sigma Gaussians (scatter_path = 3)
+against the CPU oracle: same tolerance as every other Gaussian path (rtol 1e-4, NaN mask exact)."""
+import numpy as np
+import pytest
+
+import pcr_oracle_py as O
+from conftest import load_cabi
+
+pytestmark = pytest.mark.gpu
+RT = {"Sum": 0, "Average": 3, "WeightedAverage": 4, "Count": 5}
+
+
+@pytest.fixture(scope="module")
+def A():
+    return load_cabi()
+
+
+def run_gpu(A, og, rtype, x, y, v, gl, path, own_rows=None, halo=0):
+    mask = {0: A.PLANE_SUM, 3: 3, 4: 3, 5: A.PLANE_WGT}[rtype]
+    grid = A.make_grid((og.min_x, og.min_y, og.max_x, og.max_y), cell=(og.cell_size_x, og.cell_size_y),
+                       dims=(og.width, og.height), tile=(og.tile_width, og.tile_height), own_rows=own_rows, halo=halo)
+    run = A.ReductionRun(grid, mask, path=path)
+    try:
+        run.scatter(x, y, v, glyph=gl)
+        return run.finalize(rtype), run.stats(), run
+    except Exception:
+        run.close()
+        raise
+
+
+def check(got, want, exact, what):
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN mask"
+    m = ~np.isnan(want)
+    err = np.abs(got[m].astype(np.float64) - exact[m])
+    tol = 1e-4 * np.maximum(1e-3, np.abs(exact[m]))
+    assert (err <= tol).all(), f"{what}: max rel err {np.max(err / np.maximum(1e-3, np.abs(exact[m]))):.3e}"
+
+
+CASES = [
+    dict(name="s16_r48", G=(256, 192), sigma=(16.0, 16.0), maxr=64.0, n=4000, tile=(4096, 4096)),
+    dict(name="s8_r24", G=(200, 160), sigma=(8.0, 8.0), maxr=32.0, n=6000, tile=(4096, 4096)),
+    dict(name="s4_r12", G=(192, 128), sigma=(4.0, 4.0), maxr=12.0, n=8000, tile=(4096, 4096)),
+    dict(name="s6_aniso", G=(160, 160), sigma=(6.0, 5.0), maxr=32.0, n=5000, tile=(4096, 4096)),
+    dict(name="s8_tiles", G=(192, 160), sigma=(8.0, 8.0), maxr=20.0, n=6000, tile=(64, 48)),      # taps stop at tile edges (Q4)
+    dict(name="s5_halfcell", G=(256, 128), sigma=(3.0, 3.0), maxr=32.0, n=6000, tile=(4096, 4096), cell=(0.5, -0.5)),
+]
+
+
+@pytest.mark.parametrize("rname", ["WeightedAverage", "Sum", "Count"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_moment_path_matches_oracle(A, case, rname):
+    W, H = case["G"]
+    cs = case.get("cell", (1.0, -1.0))
+    og = O.make_grid((0.0, 0.0, W * cs[0], H * abs(cs[1])), cell=cs, tile=case["tile"])
+    assert (og.width, og.height) == (W, H)
+    rng = np.random.default_rng(17)
+    n = case["n"]
+    x = rng.uniform(-2.0, og.max_x + 2.0, n)           # some points outside
+    y = rng.uniform(-2.0, og.max_y + 2.0, n)
+    x[:4] = [0.0, og.max_x, og.max_x, 0.0]             # corners: centre cell != routed cell -> direct fallback
+    y[:4] = [0.0, og.max_y, 0.0, og.max_y]
+    v = rng.normal(10.0, 3.0, n).astype(np.float32)
+    sx, sy = case["sigma"]
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=sx, sigma_y=sy, max_radius=case["maxr"])
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sx, sigma_y=sy, max_radius=case["maxr"])
+    rt = RT[rname]
+    got, st, run = run_gpu(A, og, rt, x, y, v, gl, path=3)
+    run.close()
+    assert st.path == 2, "moment path was not taken"
+    want = O.run(og, rt, x, y, v, glyph=ogl)
+    exact = O.run(og, rt, x, y, v, glyph=ogl, wide=True).astype(np.float64)
+    ref = O.Reduction(og, rt, ogl)
+    ref.ingest(x, y, v)
+    assert st.points_valid == ref.points_valid()
+    check(got, want, exact, f'{case["name"]}/{rname}')
+
+
+def test_moment_path_nonfinite_values_and_second_ingest(A):
+    og = O.make_grid((0, 0, 128, 96))
+    rng = np.random.default_rng(3)
+    n = 3000
+    x, y = rng.uniform(0, 128, n), rng.uniform(0, 96, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    v[10] = np.inf
+    v[20] = np.nan
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=8.0, max_radius=24.0)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=8.0, max_radius=24.0)
+    grid = A.make_grid((0, 0, 128, 96))
+    run = A.ReductionRun(grid, 3, path=3)
+    ref = O.Reduction(og, O.SUM, ogl)
+    try:
+        for rep in range(2):                       # state accumulates across ingests
+            run.scatter(x, y, v, glyph=gl)
+            ref.ingest(x, y, v)
+        got = run.finalize(0)
+    finally:
+        run.close()
+    want = ref.finalize()
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-4, atol=1e-5)
+
+
+def test_moment_path_row_block_shards(A):
+    """Two row-block shards (halo = r) through the moment path, merged, equal the unsharded oracle."""
+    import ctypes as C
+    W, H, split, r = 160, 128, 72, 24
+    og = O.make_grid((0, 0, W, H))
+    rng = np.random.default_rng(5)
+    n = 5000
+    x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=8.0, max_radius=float(r))
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=8.0, max_radius=float(r))
+    want = O.run(og, O.WEIGHTED_AVERAGE, x, y, v, glyph=ogl)
+    L = A.lib()
+    runs = []
+    for own in ((0, split), (split, H)):
+        g = A.make_grid((0, 0, W, H), own_rows=own, halo=r)
+        rr = A.ReductionRun(g, 3, path=3)
+        rr.scatter(x, y, v, glyph=gl)
+        assert rr.stats().path == 2
+        runs.append(rr)
+    top, bot = runs
+    for name, kind in (("d_sum", A.PLANE_SUM), ("d_wgt", A.PLANE_WGT)):
+        tp, bp = top.bufs[name].ptr.value, bot.bufs[name].ptr.value
+        A.check(L.pcr_hip_plane_merge(kind, C.c_void_p(bp + r * W * 4), C.c_void_p(tp + split * W * 4), r * W, None))
+        A.check(L.pcr_hip_plane_merge(kind, C.c_void_p(tp + (split - r) * W * 4), C.c_void_p(bp), r * W, None))
+    got = np.vstack([top.finalize(4), bot.finalize(4)])
+    for rr in runs:
+        rr.close()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    np.testing.assert_allclose(got[m], want[m], rtol=1e-4, atol=1e-6)
+
+
+def test_moment_path_refuses_what_it_cannot_represent(A):
+    og = A.make_grid((0, 0, 64, 64))
+    run = A.ReductionRun(og, 3, path=3)
+    try:
+        with pytest.raises(A.PcrHipError, match="moment path forced but not applicable"):
+            run.scatter([5.0], [5.0], [1.0], glyph=dict(type=A.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=8.0,
+                                                        rotation=0.3, max_radius=24.0))
+        with pytest.raises(A.PcrHipError, match="moment path forced but not applicable"):
+            run.scatter([5.0], [5.0], [1.0], glyph=dict(type=A.GLYPH_GAUSSIAN, sigma_x=1.0, sigma_y=1.0, max_radius=4.0))
+    finally:
+        run.close()
