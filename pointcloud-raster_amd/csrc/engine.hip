@@ -3,26 +3,63 @@
 // scatter_direct.hip / scatter_binned.hip.
 #include "engine.hpp"
 
+#include <mutex>
 #include <new>
 
 using namespace pcrhip;
 
+namespace {
+
+// One grow-only scratch arena per device, shared by every engine on it (the reference's
+// MemoryPool role, src/engine/memory_pool.cu:24-59).  A scatter borrows it for the kernels it
+// enqueues; ordering between engines on different streams is by event: the borrower's stream
+// waits for the previous borrower's last kernel, so nothing synchronizes the host in steady state
+// and a fresh pipeline never pays a multi-GB hipMalloc on its first ingest.
+struct SharedScratch {
+    std::mutex mu;
+    char* ptr = nullptr;
+    size_t cap = 0;
+    hipEvent_t last = nullptr;
+    bool has_last = false;
+};
+constexpr int kMaxDevices = 64;
+SharedScratch g_scratch[kMaxDevices];
+
+}  // namespace
+
 namespace pcrhip {
 
 int ensure_scratch(pcr_hip_engine* e, size_t bytes) {
-    if (bytes <= e->scratch_cap) return PCR_HIP_OK;
-    // grow-only; growth happens on the first ingest of a given size (outside steady state).
-    // Free after the stream drains: earlier kernels may still read the old block.
-    if (e->d_scratch) {
-        PCR_HIP_TRY(hipStreamSynchronize(e->stream));
-        PCR_HIP_TRY(hipFree(e->d_scratch));
-        e->d_scratch = nullptr;
-        e->scratch_cap = 0;
+    PCR_REQUIRE(e->device >= 0 && e->device < kMaxDevices, "scratch: device ordinal out of range");
+    SharedScratch& sp = g_scratch[e->device];
+    std::lock_guard<std::mutex> lock(sp.mu);
+    if (!sp.last) PCR_HIP_TRY(hipEventCreateWithFlags(&sp.last, hipEventDisableTiming));
+    if (bytes > sp.cap) {
+        // growth only (first ingest of a larger size): every earlier user must be done with the old block
+        PCR_HIP_TRY(hipDeviceSynchronize());
+        if (sp.ptr) PCR_HIP_TRY(hipFree(sp.ptr));
+        sp.ptr = nullptr;
+        sp.cap = 0;
+        sp.has_last = false;
+        size_t want = bytes + bytes / 8;
+        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sp.ptr), want));
+        sp.cap = want;
     }
-    size_t want = bytes + bytes / 8;
-    PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_scratch), want));
-    e->scratch_cap = want;
+    if (sp.has_last && !e->scratch_borrowed) PCR_HIP_TRY(hipStreamWaitEvent(e->stream, sp.last, 0));
+    e->d_scratch = sp.ptr;
+    e->scratch_cap = sp.cap;
+    e->scratch_borrowed = true;
     return PCR_HIP_OK;
+}
+
+// Called after a scatter has enqueued its last kernel.
+void release_scratch(pcr_hip_engine* e) {
+    if (!e->scratch_borrowed) return;
+    SharedScratch& sp = g_scratch[e->device];
+    std::lock_guard<std::mutex> lock(sp.mu);
+    if (sp.last && hipEventRecord(sp.last, e->stream) == hipSuccess) sp.has_last = true;
+    e->scratch_borrowed = false;
+    e->d_scratch = nullptr;
 }
 
 }  // namespace pcrhip
@@ -74,8 +111,9 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
     if (err == hipSuccess) err = hipMemsetAsync(e->d_touched, 0, (size_t)e->ntiles * sizeof(uint32_t), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream);
     if (err == hipSuccess && scratch_bytes) {
-        err = hipMalloc(reinterpret_cast<void**>(&e->d_scratch), scratch_bytes);
-        if (err == hipSuccess) e->scratch_cap = scratch_bytes;
+        // pre-size the device-wide arena at create time (outside any ingest)
+        if (ensure_scratch(e, scratch_bytes) != PCR_HIP_OK) err = hipErrorOutOfMemory;
+        else release_scratch(e);
     }
     if (err != hipSuccess) {
         std::string msg = std::string("engine_create: ") + hipGetErrorString(err);
@@ -92,8 +130,7 @@ int pcr_hip_engine_destroy(pcr_hip_engine* e) {
     for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (e->d_touched) (void)hipFree(e->d_touched);
     if (e->d_counters) (void)hipFree(e->d_counters);
-    if (e->d_scratch) (void)hipFree(e->d_scratch);
-    delete e;
+    delete e;              // the scratch arena is device-wide and outlives engines
     return PCR_HIP_OK;
 }
 
@@ -171,12 +208,12 @@ int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_
     rc = begin_scatter(e, n);
     if (rc) return rc;
     bool can_bin = binned_point_supported(e, plane_mask);
-    if (e->forced_path == 3 && can_bin) return binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: binned path forced but not applicable to this grid");
-    if (e->forced_path == 2 || (e->forced_path == 0 && can_bin))
-        return binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
-    return direct_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    if (e->forced_path == 1 || !can_bin) return direct_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    rc = binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    release_scratch(e);
+    return rc;
 }
 
 int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_t plane_mask,
@@ -215,14 +252,19 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
         bool can_mom = moments_supported(e, gl, plane_mask);
         if (e->forced_path == 3 && !can_mom && gl.type == PCR_HIP_GLYPH_GAUSSIAN)
             return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path forced but not applicable to this glyph");
-        if (can_mom) return moments_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+        if (can_mom) {
+            rc = moments_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+            release_scratch(e);
+            return rc;
+        }
     }
     bool can_bin = binned_glyph_supported(e, gl, plane_mask);
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: binned path forced but not applicable");
-    if (e->forced_path == 2 || (e->forced_path == 0 && can_bin))
-        return binned_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
-    return direct_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    if (e->forced_path == 1 || !can_bin) return direct_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    rc = binned_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    release_scratch(e);
+    return rc;
 }
 
 }  // extern "C"

@@ -26,14 +26,16 @@ struct pcr_hip_engine {
     std::vector<Pending> pending;
     std::map<std::string, std::pair<uint32_t, double>> kernel_ms;
 
-    // grow-only scratch for the binned path (bin counters, cursors, records)
+    // scratch of the binned / moment paths: borrowed per scatter from the device-wide arena (engine.hip)
     char* d_scratch = nullptr;
     size_t scratch_cap = 0;
+    bool scratch_borrowed = false;
 };
 
 namespace pcrhip {
 
 int ensure_scratch(pcr_hip_engine* e, size_t bytes);
+void release_scratch(pcr_hip_engine* e);
 
 // Brackets one kernel launch with events when profiling is on.
 struct ScopedKernelTimer {

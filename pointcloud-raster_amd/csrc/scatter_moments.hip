@@ -34,10 +34,10 @@ namespace {
 
 constexpr int kThreads = 1024;        // count / scatter passes
 constexpr int kMomThreads = 512;      // per-tile moment reduction (register heavy)
-constexpr int kPad = 16;              // zero padding of the tap tables (16-output sliding windows)
+constexpr int kPad = 20;              // zero padding of the tap tables (16-output windows, 4 source rows per step)
 constexpr int kTileW = 128, kTileH = 72;                 // 9216 cells: two u32 tables + index list fit the LDS
 constexpr int kTileCells = kTileW * kTileH;
-constexpr int kSortChunk = 20480;                        // records sorted per round inside LDS
+constexpr int kSortChunk = 32768;                        // records sorted per round inside LDS (u16 positions: 64 KB)
 constexpr int kMaxK = 9;
 
 struct MomPlan {
@@ -203,7 +203,7 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
     extern __shared__ unsigned lds_u[];
     unsigned* off = lds_u;                         // [kTileCells + 1]
     unsigned* cur = off + kTileCells + 1;          // [kTileCells]
-    unsigned* idx = cur + kTileCells;              // [kSortChunk]
+    unsigned short* idx = reinterpret_cast<unsigned short*>(cur + kTileCells);   // [kSortChunk] record position inside the round
     __shared__ unsigned wave_tot[kMomThreads / 64];
 
     const int bin = blockIdx.x;
@@ -219,7 +219,18 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
         const uint4* rec = records + first + cbase;
         for (int i = threadIdx.x; i < kTileCells; i += kMomThreads) cur[i] = 0;
         __syncthreads();
-        for (unsigned j = threadIdx.x; j < cn; j += kMomThreads) atomicAdd(&cur[rec[j].x], 1u);
+        // eight independent loads in flight per lane before the dependent LDS atomics
+        for (unsigned j0 = threadIdx.x; j0 < cn; j0 += 8 * kMomThreads) {
+            unsigned lc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                unsigned j = j0 + u * kMomThreads;
+                lc[u] = j < cn ? rec[j].x : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lc[u] != 0xFFFFFFFFu) atomicAdd(&cur[lc[u]], 1u);
+        }
         __syncthreads();
         // exclusive scan of cur -> off (thread t owns cells [t*kPer, (t+1)*kPer))
         unsigned s = 0;
@@ -244,7 +255,17 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
         __syncthreads();
         for (int i = threadIdx.x; i < kTileCells; i += kMomThreads) cur[i] = off[i];
         __syncthreads();
-        for (unsigned j = threadIdx.x; j < cn; j += kMomThreads) idx[atomicAdd(&cur[rec[j].x], 1u)] = j;
+        for (unsigned j0 = threadIdx.x; j0 < cn; j0 += 8 * kMomThreads) {
+            unsigned lc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                unsigned j = j0 + u * kMomThreads;
+                lc[u] = j < cn ? rec[j].x : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lc[u] != 0xFFFFFFFFu) idx[atomicAdd(&cur[lc[u]], 1u)] = (unsigned short)(j0 + u * kMomThreads);
+        }
         __syncthreads();
 
         // per cell: fold its records into P (x2) moments held in registers, write the planes
@@ -255,8 +276,8 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 #pragma unroll
             for (int p = 0; p < P; ++p) { av[p] = 0.f; aw[p] = 0.f; }
             const unsigned e0 = off[cell], e1 = off[cell + 1];
-            for (unsigned e = e0; e < e1; ++e) {
-                const uint4 rc = rec[idx[e]];
+            // fold one record into the P (x2) accumulators
+            auto fold = [&](const uint4& rc) {
                 const float val = __uint_as_float(rc.y), sx = __uint_as_float(rc.z), sy = __uint_as_float(rc.w);
                 float mx[K + 1], ny[K + 1];
                 mx[0] = expf(-(sx * sx) * inv2sx2);
@@ -274,6 +295,20 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
                         ++p;
                     }
                 }
+            };
+            // a cell holds ~3 points on average: fetch up to four records with independent loads,
+            // then fold them (otherwise every record costs one dependent L2/HBM latency)
+            for (unsigned e = e0; e < e1; e += 4) {
+                const unsigned left = e1 - e;
+                const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 b0 = rec[idx[e]];
+                const uint4 b1 = left > 1 ? rec[idx[e + 1]] : zero;
+                const uint4 b2 = left > 2 ? rec[idx[e + 2]] : zero;
+                const uint4 b3 = left > 3 ? rec[idx[e + 3]] : zero;
+                fold(b0);
+                if (left > 1) fold(b1);
+                if (left > 2) fold(b2);
+                if (left > 3) fold(b3);
             }
             const int64_t gcell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
             if (cbase == 0) {
@@ -301,13 +336,16 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 __global__ void __launch_bounds__(256)
 k_conv_col(GridDev g, int K, int r, int yblocks_per_tile, const float* __restrict__ taps_y,
            const float* __restrict__ mom, int64_t plane_stride, float* __restrict__ u_out) {
+#pragma clang fp contract(fast)      // dense tap FMAs: fused multiply-add is both faster and more accurate here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
     const int k = blockIdx.z;
     const int trow = blockIdx.y / yblocks_per_tile, yb = blockIdx.y - trow * yblocks_per_tile;
     // reference tile rows, in window coordinates
     const int t_lo = max(trow * g.th - g.st_r0, 0), t_hi = min(min((trow + 1) * g.th, g.H) - g.st_r0, g.st_rows);
-    const int y0 = t_lo + yb * 64 + wave * 16;
+    // wave-uniform by construction; readfirstlane makes it an SGPR so that the taps below are
+    // fetched with scalar loads and feed the FMAs as scalar operands
+    const int y0 = __builtin_amdgcn_readfirstlane(t_lo + yb * 64 + wave * 16);
     if (y0 >= t_hi) return;
     const int tap_w = 2 * r + 1 + 2 * kPad;
     float acc[16];
@@ -318,14 +356,24 @@ k_conv_col(GridDev g, int K, int r, int yblocks_per_tile, const float* __restric
     for (int i = 0; i < k; ++i) p0 += K + 1 - i;
     const int yi_lo = max(y0 - r, t_lo), yi_hi = min(y0 + 15 + r, t_hi - 1);
     const bool xin = x < g.W;
+    const int xc = xin ? x : 0;
     for (int l = 0; l <= K - k; ++l) {
-        const float* plane = mom + (int64_t)(p0 + l) * plane_stride;
-        const float* tl = taps_y + l * tap_w;
-        for (int yi = yi_lo; yi <= yi_hi; ++yi) {
-            const float val = xin ? plane[(int64_t)yi * g.W + x] : 0.f;
-            const float* tw = tl + (y0 - yi + r + kPad);            // dy = (y0 + j) - yi  -> index dy + r (+pad)
+        const float* __restrict__ plane = mom + (int64_t)(p0 + l) * plane_stride + xc;
+        const float* __restrict__ tl = taps_y + l * tap_w;
+        int yi = yi_lo;
+        for (; yi + 3 <= yi_hi; yi += 4) {                 // four source rows in flight per step
+            const float v0 = plane[(int64_t)(yi + 0) * g.W], v1 = plane[(int64_t)(yi + 1) * g.W];
+            const float v2 = plane[(int64_t)(yi + 2) * g.W], v3 = plane[(int64_t)(yi + 3) * g.W];
+            const float* __restrict__ tw = tl + (y0 - yi + r + kPad);   // tap of output j for row yi+u: tw[j - u]
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * val;
+            for (int j = 0; j < 16; ++j)
+                acc[j] += tw[j] * v0 + tw[j - 1] * v1 + tw[j - 2] * v2 + tw[j - 3] * v3;
+        }
+        for (; yi <= yi_hi; ++yi) {
+            const float v0 = plane[(int64_t)yi * g.W];
+            const float* __restrict__ tw = tl + (y0 - yi + r + kPad);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * v0;
         }
     }
     if (!xin) return;
@@ -341,6 +389,7 @@ k_conv_col(GridDev g, int K, int r, int yblocks_per_tile, const float* __restric
 __global__ void __launch_bounds__(256)
 k_conv_row_accum(GridDev g, int K, int r, int xblocks_per_tile, const float* __restrict__ taps_x,
                  const float* __restrict__ u_in, int64_t plane_stride, float* __restrict__ out_plane) {
+#pragma clang fp contract(fast)
     extern __shared__ float lds_f[];
     const int tcol = blockIdx.x / xblocks_per_tile, xb = blockIdx.x - tcol * xblocks_per_tile;
     const int t_lo = tcol * g.tw, t_hi = min((tcol + 1) * g.tw, g.W);
@@ -351,7 +400,8 @@ k_conv_row_accum(GridDev g, int K, int r, int xblocks_per_tile, const float* __r
     const int stride = span | 1;                       // odd: lanes (rows) hit different banks
     float* tile = lds_f;                               // [64][stride]
     float* outt = lds_f + 64 * stride;                 // [64][65]
-    const int row = threadIdx.x & 63, xq = threadIdx.x >> 6;
+    const int row = threadIdx.x & 63;
+    const int xq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // the wave index: scalar
     const int x0 = bx0 + xq * 16;
     const int tap_w = 2 * r + 1 + 2 * kPad;
     float acc[16];
@@ -361,20 +411,33 @@ k_conv_row_accum(GridDev g, int K, int r, int xblocks_per_tile, const float* __r
     for (int k = 0; k <= K; ++k) {
         const float* uk = u_in + (int64_t)k * plane_stride;
         __syncthreads();
-        for (int i = threadIdx.x; i < 64 * span; i += 256) {
-            int ry = i / span, cx = i - ry * span;
-            int gx = bx0 - r + cx, gy = by0 + ry;
-            float val = 0.f;
-            if (gx >= t_lo && gx < t_hi && gy < g.st_rows) val = uk[(int64_t)gy * g.W + gx];
-            tile[ry * stride + cx] = val;
+        // wave w loads rows w, w+4, ...; a lane walks the row in steps of 64 columns (coalesced, no division)
+        for (int ry = xq; ry < 64; ry += 4) {
+            const int gy = by0 + ry;
+            const float* urow = uk + (int64_t)gy * g.W;
+            for (int cx = threadIdx.x & 63; cx < span; cx += 64) {
+                const int gx = bx0 - r + cx;
+                float val = 0.f;
+                if (gx >= t_lo && gx < t_hi && gy < g.st_rows) val = urow[gx];
+                tile[ry * stride + cx] = val;
+            }
         }
         __syncthreads();
-        const float* tk = taps_x + k * tap_w;
-        for (int xi = xi_lo; xi <= xi_hi; ++xi) {
-            const float val = tile[row * stride + (xi - (bx0 - r))];
-            const float* tw = tk + (x0 - xi + r + kPad);
+        const float* __restrict__ tk = taps_x + k * tap_w;
+        const float* trow = tile + row * stride - (bx0 - r);
+        int xi = xi_lo;
+        for (; xi + 3 <= xi_hi; xi += 4) {
+            const float v0 = trow[xi], v1 = trow[xi + 1], v2 = trow[xi + 2], v3 = trow[xi + 3];
+            const float* __restrict__ tw = tk + (x0 - xi + r + kPad);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * val;
+            for (int j = 0; j < 16; ++j)
+                acc[j] += tw[j] * v0 + tw[j - 1] * v1 + tw[j - 2] * v2 + tw[j - 3] * v3;
+        }
+        for (; xi <= xi_hi; ++xi) {
+            const float v0 = trow[xi];
+            const float* __restrict__ tw = tk + (x0 - xi + r + kPad);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * v0;
         }
     }
 #pragma unroll
@@ -485,7 +548,7 @@ void fill_taps(std::vector<float>& t, int K, int r, double s2) {
 template <int K, unsigned MASK>
 void launch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                     float* mom_v, float* mom_w, int64_t stride) {
-    const size_t lds = ((size_t)kTileCells * 2 + 1 + kSortChunk) * sizeof(unsigned);
+    const size_t lds = ((size_t)kTileCells * 2 + 1) * sizeof(unsigned) + (size_t)kSortChunk * sizeof(unsigned short) + 16;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_moments<K, MASK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_tile_moments<K, MASK>), dim3(p.bins.nbins), dim3(kMomThreads), lds, e->stream, e->gd,
@@ -512,10 +575,13 @@ bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mas
     if (e->forced_path == 3) return true;
     // worth it when painting footprints costs more than the point-count independent convolutions:
     // ~1.5 ps per footprint cell-update (measured, LDS-tile splat) vs ~0.12 ps per cell x pair x tap
-    const double splat = (double)e->stats.points_in * (2.0 * p.r + 1) * (2.0 * p.r + 1) * 1.5e-12;
-    const double conv = (double)e->gd.W * e->gd.st_rows * p.P * (2.0 * p.r + 1) * 2.0 * 0.12e-12 +
-                        (double)e->stats.points_in * (p.P * 0.04e-9 + 0.05e-9);
-    return p.r >= 6 && conv < splat;
+    // (measured on MI355X, 4096^2: splat 1.5 ps per cell update; convolutions 0.16 ps per cell x pair x tap
+    //  for both plane kinds; moment passes 37 ps + 0.9 ps x pairs per point)
+    const double n = (double)e->stats.points_in;
+    const double splat = n * (2.0 * p.r + 1) * (2.0 * p.r + 1) * 1.5e-12;
+    const double conv = (double)e->gd.W * e->gd.st_rows * p.P * (2.0 * p.r + 1) * 1.6e-13 +
+                        n * (37e-12 + 0.91e-12 * p.P);
+    return conv < splat;
 }
 
 int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
