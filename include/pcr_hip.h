@@ -181,6 +181,29 @@ int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
 /* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */
 int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, int32_t* tiles_x, int32_t* tiles_y);
 
+/* ---- point filter.  replaces: filter_points (include/pcr/engine/filter.h:65-74; CPU src/engine/filter.cpp:34-206,
+ *      CUDA kernel_evaluate_predicates src/engine/filter_kernels.cu:22-64): AND of per-channel predicates on
+ *      Float32 channels.  Produces a byte mask (1 = keep) instead of a compacted index list; the engine applies
+ *      the mask inside its routing kernels, so a filtered ingest costs one extra byte per point. */
+#define PCR_HIP_MAX_FILTER_PREDICATES 16
+#define PCR_HIP_MAX_FILTER_SET 16          /* the reference's device limit (src/engine/filter_kernels.cu:15) */
+enum {                                      /* pcr::CompareOp numbering (include/pcr/engine/filter.h:20-29) */
+    PCR_HIP_CMP_EQUAL = 0, PCR_HIP_CMP_NOT_EQUAL = 1, PCR_HIP_CMP_LESS = 2, PCR_HIP_CMP_LESS_EQUAL = 3,
+    PCR_HIP_CMP_GREATER = 4, PCR_HIP_CMP_GREATER_EQUAL = 5, PCR_HIP_CMP_IN_SET = 6, PCR_HIP_CMP_NOT_IN_SET = 7
+};
+typedef struct pcr_hip_predicate {
+    const float* d_channel;
+    int32_t op;
+    float value;
+    int32_t set_size;
+    float set[PCR_HIP_MAX_FILTER_SET];
+} pcr_hip_predicate;
+/* d_mask[i] = all predicates hold for point i; *d_pass_count (optional, device u64, zeroed by the call) = survivors */
+int pcr_hip_filter_mask(const pcr_hip_predicate* preds, int n_pred, uint64_t n, uint8_t* d_mask,
+                        unsigned long long* d_pass_count, pcr_hip_stream s);
+/* Points with d_mask[i] == 0 are ignored by every following scatter on this engine; NULL clears it. */
+int pcr_hip_engine_set_point_mask(pcr_hip_engine* e, const uint8_t* d_mask);
+
 /* Per-kernel timing with HIP events on the engine's stream (for roofline reporting).
  * While enabled every kernel the engine launches is bracketed by two events; _read drains the
  * events (synchronizes) and returns, per kernel name, launches and summed milliseconds. */

@@ -305,6 +305,40 @@ int pcro_accumulate_glyph(const pcro_glyph* spec, int rtype, const pcro_points* 
 }
 
 /* ------------------------------------------------------------------------- */
+/* Point filter (src/engine/filter.cpp)                                        */
+/* ------------------------------------------------------------------------- */
+
+/* evaluate_predicate: filter.cpp:34-56 */
+static int eval_pred(const pcro_predicate* p, float v) {
+    int in = 0;
+    switch (p->op) {
+        case PCRO_CMP_EQUAL: return v == p->value;
+        case PCRO_CMP_NOT_EQUAL: return v != p->value;
+        case PCRO_CMP_LESS: return v < p->value;
+        case PCRO_CMP_LESS_EQUAL: return v <= p->value;
+        case PCRO_CMP_GREATER: return v > p->value;
+        case PCRO_CMP_GREATER_EQUAL: return v >= p->value;
+        case PCRO_CMP_IN_SET:
+        case PCRO_CMP_NOT_IN_SET:
+            for (int k = 0; k < p->set_size; ++k) in = in || (v == p->set[k]);   /* std::find on floats */
+            return p->op == PCRO_CMP_IN_SET ? in : !in;
+    }
+    return 0;
+}
+
+/* the AND loop of filter_points_cpu: filter.cpp:141-206 (a point passes iff every predicate holds) */
+uint64_t pcro_filter_mask(const pcro_predicate* preds, int n_pred, uint64_t n, uint8_t* mask) {
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        int ok = 1;
+        for (int k = 0; k < n_pred && ok; ++k) ok = eval_pred(&preds[k], preds[k].channel[i]);
+        mask[i] = (uint8_t)ok;
+        kept += (uint64_t)ok;
+    }
+    return kept;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Whole path for one ReductionSpec (src/engine/pipeline.cpp)                 */
 /* ------------------------------------------------------------------------- */
 

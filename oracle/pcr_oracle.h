@@ -111,6 +111,19 @@ int pcro_accumulate_glyph(const pcro_glyph* spec, int rtype, const pcro_points* 
                           int32_t tile_col_origin, int32_t tile_row_origin,
                           int32_t tile_w, int32_t tile_h);
 
+/* ---- point filter (src/engine/filter.cpp:34-56 evaluate_predicate, :141-206 AND over predicates) ---- */
+enum { PCRO_CMP_EQUAL = 0, PCRO_CMP_NOT_EQUAL, PCRO_CMP_LESS, PCRO_CMP_LESS_EQUAL, PCRO_CMP_GREATER,
+       PCRO_CMP_GREATER_EQUAL, PCRO_CMP_IN_SET, PCRO_CMP_NOT_IN_SET };   /* pcr::CompareOp, filter.h:20-29 */
+typedef struct pcro_predicate {
+    const float* channel;
+    int32_t op;
+    float value;
+    const float* set;
+    int32_t set_size;
+} pcro_predicate;
+/* mask[i] = 1 where every predicate holds; returns the number of survivors */
+uint64_t pcro_filter_mask(const pcro_predicate* preds, int n_pred, uint64_t n, uint8_t* mask);
+
 /* ---- the whole path for one ReductionSpec ---------------------------------- */
 typedef struct pcro_reduction pcro_reduction;
 

@@ -76,6 +76,38 @@ def make_points(x, y, value, direction=None, half_length=None, sigma_x=None, sig
     return Points(*vals, n), keep
 
 
+class Predicate(C.Structure):
+    _fields_ = [("channel", C.c_void_p), ("op", C.c_int32), ("value", C.c_float),
+                ("set", C.c_void_p), ("set_size", C.c_int32)]
+
+
+CMP = {"Equal": 0, "NotEqual": 1, "Less": 2, "LessEqual": 3, "Greater": 4, "GreaterEqual": 5,
+       "InSet": 6, "NotInSet": 7}
+
+
+def filter_mask(n, predicates):
+    """predicates: list of (channel array f32, op name, value or list of set values) -> (uint8 mask, kept)."""
+    keep = []
+    arr = (Predicate * max(len(predicates), 1))()
+    for k, (ch, op, val) in enumerate(predicates):
+        ch = np.ascontiguousarray(ch, dtype=np.float32)
+        keep.append(ch)
+        arr[k].channel = ch.ctypes.data
+        arr[k].op = CMP[op]
+        if op in ("InSet", "NotInSet"):
+            st = np.ascontiguousarray(val, dtype=np.float32)
+            keep.append(st)
+            arr[k].set, arr[k].set_size, arr[k].value = st.ctypes.data, len(st), 0.0
+        else:
+            arr[k].set, arr[k].set_size, arr[k].value = None, 0, float(val)
+    mask = np.zeros(n, dtype=np.uint8)
+    L = lib()
+    L.pcro_filter_mask.restype = C.c_uint64
+    L.pcro_filter_mask.argtypes = [C.POINTER(Predicate), C.c_int, C.c_uint64, C.c_void_p]
+    kept = L.pcro_filter_mask(arr, len(predicates), n, mask.ctypes.data)
+    return mask, int(kept)
+
+
 _lib = None
 _ref = None
 

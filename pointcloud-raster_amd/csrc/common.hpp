@@ -40,6 +40,7 @@ struct GridDev {
     int tw, th, tiles_x, tiles_y;
     int own_r0, own_r1;
     int st_r0, st_rows;
+    const unsigned char* mask;        // optional point filter: mask[i] == 0 -> point i is ignored
 };
 
 struct PlanesDev {
@@ -70,6 +71,7 @@ inline GridDev make_grid_dev(const pcr_hip_grid& g) {
     d.tiles_y = (g.height + g.tile_height - 1) / g.tile_height;
     d.own_r0 = g.own_row0; d.own_r1 = g.own_row1;
     d.st_r0 = g.state_row0; d.st_rows = g.state_rows;
+    d.mask = nullptr;
     return d;
 }
 
@@ -102,6 +104,9 @@ __device__ __forceinline__ bool world_to_cell(const GridDev& g, double wx, doubl
     row = r;
     return true;
 }
+
+// Point filter (FilterSpec): applied where a kernel decides a point's validity.
+__device__ __forceinline__ bool point_kept(const GridDev& g, uint64_t i) { return g.mask == nullptr || g.mask[i] != 0; }
 
 // ---- float atomics ------------------------------------------------------------
 // Sum planes: hardware global_atomic_add_f32 / ds_add_f32 (no CAS loop; built with

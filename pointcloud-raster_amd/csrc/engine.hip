@@ -160,6 +160,12 @@ int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, in
     return PCR_HIP_OK;
 }
 
+int pcr_hip_engine_set_point_mask(pcr_hip_engine* e, const uint8_t* d_mask) {
+    PCR_REQUIRE(e, "engine_set_point_mask: null engine");
+    e->gd.mask = d_mask;
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_engine_profile_enable(pcr_hip_engine* e, int on) {
     PCR_REQUIRE(e, "engine_profile_enable: null engine");
     e->profiling = on != 0;

@@ -59,9 +59,9 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
     unsigned my_valid = 0;
     // The routing is done once: pass B reads the 4-byte key written here instead of x, y (16 B).
-    auto handle = [&](double wx, double wy) -> unsigned {
+    auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
         Routed r = route(g, b, wx, wy);
-        if (r.valid) {
+        if (r.valid && point_kept(g, i)) {
             atomicAdd(&lds_hist[r.bin], 1u);
             ++my_valid;
             if (!one_tile) touch_tile(g, touched, r.row, r.col);
@@ -86,8 +86,9 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                unsigned ka = handle(xs[u].x, ys[u].x);
-                unsigned kb = handle(xs[u].y, ys[u].y);
+                const uint64_t i = base + 2ull * (p0 + u * kThreads);
+                unsigned ka = handle(i, xs[u].x, ys[u].x);
+                unsigned kb = handle(i + 1, xs[u].y, ys[u].y);
                 k2[p0 + u * kThreads] = make_uint2(ka, kb);
             }
         }
@@ -95,7 +96,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
             uint64_t i = base + k;
             if (i >= n) break;
-            keys[i] = handle(x[i], y[i]);
+            keys[i] = handle(i, x[i], y[i]);
         }
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);

@@ -37,7 +37,7 @@ k_point_direct(GridDev g, PlanesDev pl, const double* __restrict__ x, const doub
         int col = 0, row = 0;
         float val = 0.0f;
         if (i < n) {
-            valid = world_to_cell(g, x[i], y[i], col, row);
+            valid = point_kept(g, i) && world_to_cell(g, x[i], y[i], col, row);
             valid = valid && row >= g.own_r0 && row < g.own_r1;
             if (MASK & (PCR_HIP_PLANE_SUM | PCR_HIP_PLANE_MAX | PCR_HIP_PLANE_MIN)) val = v[i];
         }
@@ -85,7 +85,7 @@ k_gauss_direct(GridDev g, GlyphDev gl, PlanesDev pl, const double* __restrict__ 
         GaussParams q{};
         if (i < n) {
             PointGeom pg = point_geom(g, x[i], y[i]);
-            valid = pg.valid;
+            valid = pg.valid && point_kept(g, i);
             if (valid) {
                 q = gauss_params(g, gl, pg, v[i], i);
                 touch_tile(g, touched, pg.row, pg.col);
@@ -121,7 +121,7 @@ k_line_direct(GridDev g, GlyphDev gl, PlanesDev pl, const double* __restrict__ x
         bool valid = false;
         if (i < n) {
             PointGeom pg = point_geom(g, x[i], y[i]);
-            valid = pg.valid;
+            valid = pg.valid && point_kept(g, i);
             if (valid) {
                 LineParams q = line_params(g, gl, pg, v[i], i);
                 touch_tile(g, touched, pg.row, pg.col);

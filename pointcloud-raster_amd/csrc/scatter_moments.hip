@@ -68,7 +68,7 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         double wx = x[i], wy = y[i];
         PointGeom pg = point_geom(g, wx, wy);
         unsigned key = 0xFFFFFFFFu;
-        if (pg.valid) {
+        if (pg.valid && point_kept(g, i)) {
             ++my_valid;
             touch_tile(g, touched, pg.row, pg.col);
             int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);

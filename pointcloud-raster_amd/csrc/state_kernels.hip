@@ -179,6 +179,48 @@ k_finalize_group(GridDev g, PlanesDev pl, unsigned need, const uint32_t* __restr
     }
 }
 
+// FilterSpec evaluation: AND of predicates (evaluate_predicate, src/engine/filter.cpp:34-56).
+struct PredSet {
+    int n;
+    pcr_hip_predicate p[PCR_HIP_MAX_FILTER_PREDICATES];
+};
+
+__device__ __forceinline__ bool eval_pred(const pcr_hip_predicate& pr, float v) {
+    switch (pr.op) {
+        case PCR_HIP_CMP_EQUAL: return v == pr.value;
+        case PCR_HIP_CMP_NOT_EQUAL: return v != pr.value;
+        case PCR_HIP_CMP_LESS: return v < pr.value;
+        case PCR_HIP_CMP_LESS_EQUAL: return v <= pr.value;
+        case PCR_HIP_CMP_GREATER: return v > pr.value;
+        case PCR_HIP_CMP_GREATER_EQUAL: return v >= pr.value;
+        case PCR_HIP_CMP_IN_SET: {
+            bool in = false;
+            for (int k = 0; k < pr.set_size; ++k) in = in || (v == pr.set[k]);
+            return in;
+        }
+        case PCR_HIP_CMP_NOT_IN_SET: {
+            bool in = false;
+            for (int k = 0; k < pr.set_size; ++k) in = in || (v == pr.set[k]);
+            return !in;
+        }
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_filter_mask(PredSet ps, uint64_t n, unsigned char* __restrict__ mask, unsigned long long* __restrict__ pass_count) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n_round = ((n + 63) / 64) * 64;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += stride) {
+        bool keep = i < n;
+        if (keep)
+            for (int k = 0; k < ps.n; ++k) keep = keep && eval_pred(ps.p[k], ps.p[k].d_channel[i]);
+        if (i < n) mask[i] = keep ? 1 : 0;
+        unsigned long long m = __ballot(keep);
+        if (pass_count && (threadIdx.x & 63) == 0 && m) atomicAdd(pass_count, (unsigned long long)__popcll(m));
+    }
+}
+
 template <int RT>
 int launch_finalize(const GridDev& g, const float* pa, const float* pb, const uint32_t* touched,
                     float* out, hipStream_t s) {
@@ -264,6 +306,28 @@ int pcr_hip_plane_merge(uint32_t plane_kind, float* d_dst, const float* d_src, i
         default: return fail(PCR_HIP_INVALID_ARGUMENT, "plane_merge: exactly one PCR_HIP_PLANE_* kind expected");
     }
     return merge_kind(kind, d_dst, d_src, cells, static_cast<hipStream_t>(s));
+}
+
+int pcr_hip_filter_mask(const pcr_hip_predicate* preds, int n_pred, uint64_t n, uint8_t* d_mask,
+                        unsigned long long* d_pass_count, pcr_hip_stream s) {
+    PCR_REQUIRE(n_pred >= 0 && n_pred <= PCR_HIP_MAX_FILTER_PREDICATES, "filter_points: too many predicates (max 16)");
+    PCR_REQUIRE(n_pred == 0 || preds, "filter_points: null predicate list");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    if (d_pass_count) PCR_HIP_TRY(hipMemsetAsync(d_pass_count, 0, sizeof(unsigned long long), st));
+    if (n == 0) return PCR_HIP_OK;
+    PCR_REQUIRE(d_mask, "filter_points: null mask");
+    PredSet ps;
+    ps.n = n_pred;
+    for (int k = 0; k < n_pred; ++k) {
+        PCR_REQUIRE(preds[k].d_channel, "filter_points: null channel pointer");
+        PCR_REQUIRE(preds[k].op >= 0 && preds[k].op <= PCR_HIP_CMP_NOT_IN_SET, "filter_points: unknown compare op");
+        PCR_REQUIRE(preds[k].set_size >= 0 && preds[k].set_size <= PCR_HIP_MAX_FILTER_SET,
+                    "filter_points: value_set larger than 16 entries");
+        ps.p[k] = preds[k];
+    }
+    hipLaunchKernelGGL(k_filter_mask, dim3(grid_for((int64_t)n)), dim3(kBlock), 0, st, ps, n, d_mask, d_pass_count);
+    PCR_HIP_TRY(hipGetLastError());
+    return PCR_HIP_OK;
 }
 
 int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <map>
+#include <vector>
 
 namespace pcr {
 
@@ -234,9 +235,20 @@ struct Pipeline::Impl {
     Status ingest(const PointCloud& cloud) {
         const size_t n = cloud.count();
         if (n == 0) return Status::success();
-        if (!cfg.filter.empty())
-            return Status::error(StatusCode::NotImplemented,
-                "pipeline: FilterSpec is not supported by this build (filter stage is outside the accelerated path)");
+        // filter predicates: same checks and messages as filter_points (src/engine/filter.cpp:101-123)
+        for (const auto& pr : cfg.filter.predicates) {
+            if (!cloud.channel_data(pr.channel_name))
+                return Status::error(StatusCode::InvalidArgument, "filter_points: channel not found: " + pr.channel_name);
+            const ChannelDesc* d = cloud.channel(pr.channel_name);
+            if (!d || d->dtype != DataType::Float32)
+                return Status::error(StatusCode::InvalidArgument,
+                                     "filter_points: only Float32 channels supported for filtering");
+            if (pr.value_set.size() > PCR_HIP_MAX_FILTER_SET)
+                return Status::error(StatusCode::InvalidArgument,
+                                     "filter_points: value_set larger than 16 entries is not supported on the device");
+        }
+        if (cfg.filter.predicates.size() > PCR_HIP_MAX_FILTER_PREDICATES)
+            return Status::error(StatusCode::InvalidArgument, "filter_points: more than 16 predicates");
 
         // validate every reduction before touching state
         for (const auto& r : cfg.reductions) {
@@ -265,6 +277,45 @@ struct Pipeline::Impl {
             if (!d || d->dtype != DataType::Float32) return Status::success();   // -> GlyphSpec default
             return device_array(cloud.channel_data(name), loc, n * sizeof(float), "ch:" + name, out);
         };
+
+        // Filter stage, on the device: a byte mask evaluated once per ingest and honoured by every
+        // routing kernel.  (The reference gathers values by filter index but routes the UNFILTERED
+        // cloud, pipeline.cpp:436-438 vs :662, which is why its own WithFilter test is disabled;
+        // here a filtered-out point simply does not exist for any reduction.)
+        size_t kept = n;
+        if (!cfg.filter.empty()) {
+            std::vector<pcr_hip_predicate> preds(cfg.filter.predicates.size());
+            for (size_t k = 0; k < preds.size(); ++k) {
+                const FilterPredicate& pr = cfg.filter.predicates[k];
+                const void* ch = nullptr;
+                if (!(s = f32_channel(pr.channel_name, &ch)).ok()) return s;
+                preds[k].d_channel = static_cast<const float*>(ch);
+                preds[k].op = static_cast<int32_t>(pr.op);
+                preds[k].value = pr.value;
+                preds[k].set_size = static_cast<int32_t>(pr.value_set.size());
+                for (size_t j = 0; j < pr.value_set.size(); ++j) preds[k].set[j] = pr.value_set[j];
+            }
+            detail::Buffer& mb = staging["filter:mask"];
+            if (mb.bytes() < n + 8) {
+                if (!(s = detail::hip_status(pcr_hip_stream_synchronize(stream))).ok()) return s;
+                if (!(s = mb.allocate(n + n / 8 + 16, MemoryLocation::Device)).ok()) return s;
+            }
+            // layout: [u64 survivor count][mask bytes]
+            auto* d_count = static_cast<unsigned long long*>(mb.data());
+            auto* d_mask = static_cast<uint8_t*>(mb.data()) + 8;
+            s = detail::hip_status(pcr_hip_filter_mask(preds.data(), (int)preds.size(), n, d_mask, d_count, stream));
+            if (!s.ok()) return s;
+            unsigned long long h_count = 0;
+            if (!(s = detail::hip_status(pcr_hip_memcpy_d2h(&h_count, d_count, sizeof h_count, stream))).ok()) return s;
+            if (!(s = detail::hip_status(pcr_hip_stream_synchronize(stream))).ok()) return s;
+            kept = (size_t)h_count;
+            if (kept == 0) return Status::success();             // pipeline.cpp:349-353
+            pcr_hip_engine_set_point_mask(engine, d_mask);
+        }
+        struct MaskGuard {
+            pcr_hip_engine* e;
+            ~MaskGuard() { pcr_hip_engine_set_point_mask(e, nullptr); }
+        } mask_guard{engine};
 
         for (auto& gr : groups) {
             const void* dv = nullptr;
@@ -307,7 +358,7 @@ struct Pipeline::Impl {
             if (!s.ok()) return s;
         }
 
-        points += n;
+        points += kept;                 // points_processed += filtered_count (pipeline.cpp:749)
         collections++;
         if (callback) {
             ProgressInfo info = stats();

@@ -40,6 +40,11 @@ class Glyph(C.Structure):
                 ("d_sigma_x", C.c_void_p), ("d_sigma_y", C.c_void_p), ("d_rotation", C.c_void_p)]
 
 
+class Predicate(C.Structure):
+    _fields_ = [("d_channel", C.c_void_p), ("op", C.c_int32), ("value", C.c_float), ("set_size", C.c_int32),
+                ("set", C.c_float * 16)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_double)]
 
@@ -93,6 +98,8 @@ SYMBOLS = {
     "pcr_hip_engine_set_path": [_VP, C.c_int],
     "pcr_hip_engine_stats": [_VP, C.POINTER(ScatterStats)],
     "pcr_hip_engine_tile_touched": [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "pcr_hip_filter_mask": [C.POINTER(Predicate), C.c_int, _U64, _VP, _VP, _VP],
+    "pcr_hip_engine_set_point_mask": [_VP, _VP],
     "pcr_hip_engine_profile_enable": [_VP, C.c_int],
     "pcr_hip_engine_profile_read": [_VP, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int), C.c_int],
     "pcr_hip_scatter_point": [_VP, _U32, C.POINTER(Planes), _VP, _VP, _VP, _U64],

@@ -120,14 +120,18 @@ def test_error_messages_match_reference():
     assert pipe is not None
     with pytest.raises(RuntimeError, match="at least one reduction"):
         pipe.validate()
-    # filter: refused loudly instead of silently ignored
+    # filter on a missing / non-Float32 channel: filter_points' messages (src/engine/filter.cpp:101-123)
     cfg = config_for(og, [spec("Sum")])
     f = pcr.FilterSpec()
-    f.add("value", pcr.CompareOp.Greater, 0.5)
+    f.add("classification", pcr.CompareOp.Greater, 0.5)
     cfg.filter = f
     pipe = pcr.Pipeline.create(cfg)
-    with pytest.raises(RuntimeError, match="FilterSpec is not supported"):
-        pipe.ingest(cloud_from([1.0], [1.0], {"value": [1]}))
+    c = cloud_from([1.0], [1.0], {"value": [1]})
+    with pytest.raises(RuntimeError, match="filter_points: channel not found: classification"):
+        pipe.ingest(c)
+    c.add_channel("classification", pcr.DataType.Int32)
+    with pytest.raises(RuntimeError, match="only Float32 channels supported for filtering"):
+        pipe.ingest(c)
     # output_path: result still produced, GeoTIFF refused
     cfg = config_for(og, [spec("Sum")], output_path="/tmp/out.tif")
     pipe = pcr.Pipeline.create(cfg)
