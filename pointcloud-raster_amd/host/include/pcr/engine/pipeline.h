@@ -108,6 +108,7 @@ public:
     std::vector<PlaneView> state_planes() const;
     void* tile_touched_device(int* tiles_x, int* tiles_y) const;
     Status synchronize();
+    void* stream_handle() const;                 // the hipStream_t every kernel of this pipeline runs on (may be null)
     // per-kernel HIP-event timing of the scatter kernels (roofline reporting)
     struct KernelTime { std::string name; unsigned launches; double total_ms; };
     void profile_enable(bool on);

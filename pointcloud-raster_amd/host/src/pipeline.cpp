@@ -529,6 +529,7 @@ void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
 }
 
 Status Pipeline::synchronize() { return detail::hip_status(pcr_hip_stream_synchronize(impl_->stream)); }
+void* Pipeline::stream_handle() const { return impl_->stream; }
 
 void Pipeline::profile_enable(bool on) { pcr_hip_engine_profile_enable(impl_->engine, on ? 1 : 0); }
 

@@ -135,6 +135,7 @@ void bind_engine(py::module_& m) {
             return py::make_tuple(reinterpret_cast<uintptr_t>(d), tx, ty);
         })
         .def("synchronize", [](Pipeline& p) { raise_if_error(p.synchronize()); })
+        .def("stream_ptr", [](const Pipeline& p) { return reinterpret_cast<uintptr_t>(p.stream_handle()); })
         .def("profile_enable", &Pipeline::profile_enable)
         .def("profile_read", [](Pipeline& p, bool reset) {
             py::dict d;

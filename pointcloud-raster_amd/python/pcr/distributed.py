@@ -151,12 +151,22 @@ class ShardedPipeline:
         if self.world == 1:
             return
         planes = self._plane_tensors()
-        self.pipe.synchronize()                      # scatter kernels ran on the engine's stream
-        if self.halo > 0:
-            exchange_halos(planes, self.own, self.pipe.state_row_begin(), self.halo,
-                           self.rank, self.world, blocks=self.blocks, group=self.group)
-        allreduce_touched(self._touched, self.group)
-        torch.cuda.current_stream().synchronize()    # finalize runs on the engine's stream
+        # Run the collectives ON the engine's stream (wrapped as a torch ExternalStream): RCCL orders
+        # itself after the scatter kernels and before the finalize kernels by stream order alone, no
+        # host synchronisation inside the step.  (gloo staging copies synchronise by themselves.)
+        ptr = self.pipe.stream_ptr()
+        if ptr:
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(ptr))
+        else:                                        # pipeline on the null stream: plain host syncs
+            self.pipe.synchronize()
+            ctx = torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            if self.halo > 0:
+                exchange_halos(planes, self.own, self.pipe.state_row_begin(), self.halo,
+                               self.rank, self.world, blocks=self.blocks, group=self.group)
+            allreduce_touched(self._touched, self.group)
+        if not ptr:
+            torch.cuda.current_stream().synchronize()
 
     def finalize(self):
         self.exchange()
