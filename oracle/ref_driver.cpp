@@ -6,7 +6,8 @@
 //                                    CMakeLists.txt:162-165)
 //     src/ops/reduction_registry.cpp
 //     src/engine/accumulator.cpp
-// into oracle/_ref/libpcr_ref.so.  Those three files link without anything the image
+//     src/io/tile_state_io.cpp      (the `.pcrt` checkpoint writer / reader)
+// into oracle/_ref/libpcr_ref.so.  Those files link without anything the image
 // lacks.  The rest of the reference pipeline (src/core/types.cpp -> <proj.h>,
 // src/io/grid_io.cpp -> GDAL, src/engine/pipeline.cpp -> both + memory_pool.cu) would
 // need stand-in headers/libraries and is therefore treated as unbuildable here; its
@@ -23,10 +24,12 @@
 #include "pcr/engine/glyph.h"
 #include "pcr/engine/glyph_kernels.h"
 #include "pcr/engine/tile_router.h"
+#include "pcr/io/tile_state_io.h"
 #include "pcr/ops/reduction_registry.h"
 
 #include "pcr_oracle.h"
 
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -121,6 +124,37 @@ int pcr_ref_accumulate_glyph(const pcro_glyph* spec, int rtype, const pcro_point
     return ret(pcr::accumulate_glyph(gs, static_cast<pcr::ReductionType>(rtype), b, state,
                                      tile_cells, cfg, tile_col_origin, tile_row_origin,
                                      tile_w, tile_h, nullptr));
+}
+
+// src/io/tile_state_io.cpp: the reference's own `.pcrt` writer / reader.
+int pcr_ref_write_tile_state(const char* path, int tile_row, int tile_col, int cols, int rows, int state_floats,
+                             int rtype, const float* state) {
+    pcr::TileIndex t;
+    t.row = tile_row;
+    t.col = tile_col;
+    return ret(pcr::write_tile_state(path, t, cols, rows, state_floats, static_cast<pcr::ReductionType>(rtype), state));
+}
+
+int pcr_ref_read_tile_state(const char* path, int* tile_row, int* tile_col, int* cols, int* rows, int* state_floats,
+                            int* rtype, float* state /* may be null: header only */) {
+    pcr::TileIndex t;
+    pcr::ReductionType type;
+    pcr::Status s = state ? pcr::read_tile_state(path, t, *cols, *rows, *state_floats, type, state)
+                          : pcr::read_tile_state_header(path, t, *cols, *rows, *state_floats, type);
+    if (s.ok()) {
+        *tile_row = t.row;
+        *tile_col = t.col;
+        *rtype = static_cast<int>(type);
+    }
+    return ret(s);
+}
+
+void pcr_ref_tile_state_filename(const char* dir, int tile_row, int tile_col, char* out, int cap) {
+    pcr::TileIndex t;
+    t.row = tile_row;
+    t.col = tile_col;
+    std::string p = pcr::tile_state_filename(dir, t);
+    std::snprintf(out, cap, "%s", p.c_str());
 }
 
 }  // extern "C"

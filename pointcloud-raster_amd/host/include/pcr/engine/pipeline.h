@@ -95,6 +95,15 @@ public:
     const Grid* result() const;
     ProgressInfo stats() const;
 
+    // ---- checkpoint / resume in the reference's `.pcrt` tile-state format (pcr/io/tile_state_io.h).
+    // save_state writes one file per touched reference tile and ReductionSpec (directly into `dir` for a
+    // single reduction -- the reference's layout -- else into dir/reduction_<i>/); load_state sets the
+    // device state from such files (also ones written by the reference) and marks their tiles touched.
+    // An empty `dir` means PipelineConfig::state_dir.  PipelineConfig::resume = true loads at create().
+    // Unlike the reference, finalize() never writes state files implicitly.
+    Status save_state(const std::string& dir = "");
+    Status load_state(const std::string& dir = "");
+
     // ---- extensions for row-block sharded runs (halo exchange is driven by the caller,
     //      e.g. torch.distributed over RCCL: see pcr/distributed.py) -------------------------
     struct PlaneView {

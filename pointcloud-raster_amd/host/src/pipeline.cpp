@@ -14,11 +14,13 @@
 #include "buffer.h"
 #include "pcr/core/grid.h"
 #include "pcr/core/point_cloud.h"
+#include "pcr/io/tile_state_io.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <filesystem>
 #include <map>
 #include <vector>
 
@@ -438,6 +440,153 @@ struct Pipeline::Impl {
         return Status::success();
     }
 
+    // ---- `.pcrt` checkpoints ---------------------------------------------------------------
+    // planes a reduction's reference state is made of, in the reference's field order
+    // (builtin_ops.h: Sum{sum}, Max{val}, Min{val}, Count{count}, Average{sum,count}, WeightedAverage{wsum,wgt})
+    static int state_planes_of(ReductionType t, int out[2]) {
+        switch (t) {
+            case ReductionType::Sum: out[0] = 0; return 1;
+            case ReductionType::Count: out[0] = 1; return 1;
+            case ReductionType::Max: out[0] = 2; return 1;
+            case ReductionType::Min: out[0] = 3; return 1;
+            default: out[0] = 0; out[1] = 1; return 2;
+        }
+    }
+
+    std::string reduction_dir(const std::string& dir, size_t r) const {
+        return outputs.size() == 1 ? dir : dir + "/reduction_" + std::to_string(r);
+    }
+
+    Status checkpoint_dir(const std::string& dir_in, std::string* dir) const {
+        *dir = dir_in.empty() ? cfg.state_dir : dir_in;
+        if (dir->empty()) return Status::error(StatusCode::InvalidArgument, "pipeline: no state directory given");
+        if (own_rows() != hg.height)
+            return Status::error(StatusCode::NotImplemented, "pipeline: tile-state checkpoints of a row-block shard are not supported");
+        return Status::success();
+    }
+
+    // host copies of every group's planes + the touched flags
+    Status download_state(std::vector<std::vector<float>> (&hp)[4], std::vector<uint32_t>& touched) {
+        const size_t cells = (size_t)hg.width * hg.height;
+        for (int p = 0; p < 4; ++p) hp[p].assign(groups.size(), {});
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (int p = 0; p < 4; ++p) {
+                if (!(groups[gi].mask & kPlaneBits[p])) continue;
+                hp[p][gi].resize(cells);
+                Status s = detail::hip_status(pcr_hip_memcpy_d2h(hp[p][gi].data(), groups[gi].planes[p].data(),
+                                                                  cells * sizeof(float), stream));
+                if (!s.ok()) return s;
+            }
+        uint32_t* d_touched = nullptr;
+        int tx = 0, ty = 0;
+        Status s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, &tx, &ty));
+        if (!s.ok()) return s;
+        touched.resize((size_t)tx * ty);
+        s = detail::hip_status(pcr_hip_memcpy_d2h(touched.data(), d_touched, touched.size() * 4, stream));
+        if (!s.ok()) return s;
+        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    }
+
+    Status save_state(const std::string& dir_in) {
+        std::string dir;
+        Status s = checkpoint_dir(dir_in, &dir);
+        if (!s.ok()) return s;
+        std::vector<std::vector<float>> hp[4];
+        std::vector<uint32_t> touched;
+        if (!(s = download_state(hp, touched)).ok()) return s;
+        const GridConfig& g = cfg.grid;
+        const int tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
+        const int tiles_y = (g.height + g.tile_height - 1) / g.tile_height;
+        std::error_code ec;
+        std::vector<float> buf;
+        for (size_t r = 0; r < outputs.size(); ++r) {
+            const std::string rdir = reduction_dir(dir, r);
+            std::filesystem::create_directories(rdir, ec);
+            if (ec) return Status::error(StatusCode::IoError, "pipeline: cannot create " + rdir);
+            int pl[2];
+            const int k = state_planes_of(outputs[r].type, pl);
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < tiles_x; ++tx) {
+                    if (!touched[(size_t)ty * tiles_x + tx]) continue;          // only tiles that have state
+                    const int c0 = tx * g.tile_width, r0 = ty * g.tile_height;
+                    const int nc = std::min(g.tile_width, g.width - c0), nr = std::min(g.tile_height, g.height - r0);
+                    buf.resize((size_t)k * nc * nr);
+                    for (int f = 0; f < k; ++f) {
+                        const std::vector<float>& plane = hp[pl[f]][outputs[r].group];
+                        for (int y = 0; y < nr; ++y)
+                            std::copy_n(plane.data() + (size_t)(r0 + y) * g.width + c0, nc,
+                                        buf.data() + ((size_t)f * nr + y) * nc);
+                    }
+                    TileIndex ti;
+                    ti.row = ty;
+                    ti.col = tx;
+                    s = write_tile_state(tile_state_filename(rdir, ti), ti, nc, nr, k, outputs[r].type, buf.data());
+                    if (!s.ok()) return s;
+                }
+        }
+        return Status::success();
+    }
+
+    Status load_state(const std::string& dir_in) {
+        std::string dir;
+        Status s = checkpoint_dir(dir_in, &dir);
+        if (!s.ok()) return s;
+        std::vector<std::vector<float>> hp[4];
+        std::vector<uint32_t> touched;
+        if (!(s = download_state(hp, touched)).ok()) return s;
+        const GridConfig& g = cfg.grid;
+        const int tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
+        const int tiles_y = (g.height + g.tile_height - 1) / g.tile_height;
+        std::vector<float> buf;
+        size_t loaded = 0;
+        for (size_t r = 0; r < outputs.size(); ++r) {
+            const std::string rdir = reduction_dir(dir, r);
+            int pl[2];
+            const int k = state_planes_of(outputs[r].type, pl);
+            for (int ty = 0; ty < tiles_y; ++ty)
+                for (int tx = 0; tx < tiles_x; ++tx) {
+                    TileIndex ti;
+                    ti.row = ty;
+                    ti.col = tx;
+                    const std::string path = tile_state_filename(rdir, ti);
+                    std::error_code ec;
+                    if (!std::filesystem::exists(path, ec)) continue;
+                    const int c0 = tx * g.tile_width, r0 = ty * g.tile_height;
+                    const int nc = std::min(g.tile_width, g.width - c0), nr = std::min(g.tile_height, g.height - r0);
+                    TileIndex ft;
+                    int fc = 0, fr = 0, fk = 0;
+                    ReductionType ftype;
+                    // a file that does not describe this tile of this reduction is ignored, like the
+                    // reference's tile manager does (src/engine/tile_manager.cpp:272-320)
+                    if (!read_tile_state_header(path, ft, fc, fr, fk, ftype).ok()) continue;
+                    if (fc != nc || fr != nr || fk != k || ftype != outputs[r].type || ft.row != ty || ft.col != tx) continue;
+                    buf.resize((size_t)k * nc * nr);
+                    if (!read_tile_state(path, ft, fc, fr, fk, ftype, buf.data()).ok()) continue;
+                    for (int f = 0; f < k; ++f) {
+                        std::vector<float>& plane = hp[pl[f]][outputs[r].group];
+                        for (int y = 0; y < nr; ++y)
+                            std::copy_n(buf.data() + ((size_t)f * nr + y) * nc, nc,
+                                        plane.data() + (size_t)(r0 + y) * g.width + c0);
+                    }
+                    touched[(size_t)ty * tiles_x + tx] = 1;
+                    ++loaded;
+                }
+        }
+        if (!loaded) return Status::success();
+        const size_t cells = (size_t)g.width * g.height;
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (int p = 0; p < 4; ++p)
+                if (groups[gi].mask & kPlaneBits[p]) {
+                    s = detail::hip_status(pcr_hip_memcpy_h2d(groups[gi].planes[p].data(), hp[p][gi].data(),
+                                                              cells * sizeof(float), stream));
+                    if (!s.ok()) return s;
+                }
+        uint32_t* d_touched = nullptr;
+        if (!(s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, nullptr, nullptr))).ok()) return s;
+        if (!(s = detail::hip_status(pcr_hip_memcpy_h2d(d_touched, touched.data(), touched.size() * 4, stream))).ok()) return s;
+        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    }
+
     ProgressInfo stats() const {
         ProgressInfo info;
         info.collections_processed = collections;
@@ -464,6 +613,7 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
     p->impl_ = std::make_unique<Impl>();
     p->impl_->cfg = config;
     Status s = p->impl_->init();
+    if (s.ok() && config.resume && !config.state_dir.empty()) s = p->impl_->load_state(config.state_dir);
     if (!s.ok()) {
         g_create_error = s.message;
         std::fprintf(stderr, "Error: %s\n", s.message.c_str());    // loud: there is no fallback path
@@ -527,6 +677,9 @@ void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
     if (tiles_y) *tiles_y = ty;
     return d;
 }
+
+Status Pipeline::save_state(const std::string& dir) { return impl_->save_state(dir); }
+Status Pipeline::load_state(const std::string& dir) { return impl_->load_state(dir); }
 
 Status Pipeline::synchronize() { return detail::hip_status(pcr_hip_stream_synchronize(impl_->stream)); }
 void* Pipeline::stream_handle() const { return impl_->stream; }

@@ -119,6 +119,10 @@ void bind_engine(py::module_& m) {
         .def("set_progress_callback", &Pipeline::set_progress_callback)
         .def("result", &Pipeline::result, py::return_value_policy::reference_internal)
         .def("stats", &Pipeline::stats)
+        .def("save_state", [](Pipeline& p, const std::string& dir) { raise_if_error(p.save_state(dir)); },
+             py::arg("dir") = "")
+        .def("load_state", [](Pipeline& p, const std::string& dir) { raise_if_error(p.load_state(dir)); },
+             py::arg("dir") = "")
         // extensions for row-block sharded (multi-GPU) runs
         .def("halo_rows", &Pipeline::halo_rows)
         .def("state_row_begin", &Pipeline::state_row_begin)

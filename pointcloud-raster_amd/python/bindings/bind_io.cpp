@@ -6,6 +6,7 @@
 #include "pcr/core/grid.h"
 #include "pcr/core/grid_config.h"
 #include "pcr/core/point_cloud.h"
+#include "pcr/io/tile_state_io.h"
 
 #include <vector>
 
@@ -42,6 +43,34 @@ struct PointCloudReader {};
 }  // namespace
 
 void bind_io(py::module_& m) {
+    // `.pcrt` tile-state files (the reference's checkpoint format) -- implemented, unlike the rest of I/O
+    m.def("write_tile_state", [](const std::string& path, int tile_row, int tile_col,
+                                 py::array_t<float, py::array::c_style | py::array::forcecast> state,
+                                 ReductionType type) {
+        auto b = state.request();
+        if (b.ndim != 3) throw std::runtime_error("write_tile_state: state must be [state_floats, rows, cols]");
+        TileIndex t;
+        t.row = tile_row;
+        t.col = tile_col;
+        raise_if_error(write_tile_state(path, t, (int)b.shape[2], (int)b.shape[1], (int)b.shape[0], type,
+                                        static_cast<const float*>(b.ptr)));
+    }, py::arg("path"), py::arg("tile_row"), py::arg("tile_col"), py::arg("state"), py::arg("type"));
+    m.def("read_tile_state", [](const std::string& path) {
+        TileIndex t;
+        int cols = 0, rows = 0, k = 0;
+        ReductionType type;
+        raise_if_error(read_tile_state_header(path, t, cols, rows, k, type));
+        py::array_t<float> out({k, rows, cols});
+        raise_if_error(read_tile_state(path, t, cols, rows, k, type, out.mutable_data()));
+        return py::make_tuple(t.row, t.col, out, type);
+    }, py::arg("path"));
+    m.def("tile_state_filename", [](const std::string& dir, int tile_row, int tile_col) {
+        TileIndex t;
+        t.row = tile_row;
+        t.col = tile_col;
+        return tile_state_filename(dir, t);
+    });
+
     py::enum_<PointCloudFormat>(m, "PointCloudFormat")
         .value("PCR_Binary", PointCloudFormat::PCR_Binary).value("CSV", PointCloudFormat::CSV)
         .value("LAS", PointCloudFormat::LAS).value("LAZ", PointCloudFormat::LAZ)

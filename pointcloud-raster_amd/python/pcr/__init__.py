@@ -21,6 +21,7 @@ from ._pcr import (  # noqa: E402,F401
     ReductionSpec, ReductionType, Status, StatusCode, TileIndex,
     device_count, device_name, pipeline_create_error,
     read_geotiff_info, read_point_cloud, read_point_cloud_info, write_geotiff, write_point_cloud,
+    read_tile_state, tile_state_filename, write_tile_state,
 )
 
 
@@ -89,4 +90,5 @@ __all__ = [
     "GeoTiffOptions", "write_geotiff", "read_geotiff_info",
     "PointCloudInfo", "read_point_cloud", "write_point_cloud", "read_point_cloud_info", "PointCloudReader",
     "DeviceArrayView", "device_count", "device_name", "pipeline_create_error",
+    "read_tile_state", "write_tile_state", "tile_state_filename",
 ]
