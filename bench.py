@@ -149,6 +149,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+        # communicator set-up is not part of any step
+        warm = torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(warm)
+        dist.barrier()
 
     G, n = args.grid, args.points
     H = G * world                                          # rows: one G-row block per GPU
@@ -161,6 +165,9 @@ def main():
     cfg.reductions = make_specs(args.workload)
     cfg.result_location = pcr.MemoryLocation.Host if args.host_result else pcr.MemoryLocation.Device
     cfg.scatter_path = {"auto": 0, "direct": 1, "binned": 2, "moments": 3}[args.path]
+    # scratch arena (routing keys + records) sized at create, outside the clock, as the reference sizes
+    # its MemoryPool in Pipeline::create (src/engine/pipeline.cpp:167-184)
+    cfg.gpu_pool_size_bytes = 16 * n + (64 << 20)
 
     # this rank's rows [rank*G, (rank+1)*G) <=> world y in (H - (rank+1)*G, H - rank*G)
     y_hi = float(H - rank * G)
@@ -216,7 +223,7 @@ def main():
             "metric": "Mpts/s ingest->finalize",
             "value": round(value, 2), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 state, f64 coordinates",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n,
                        "grid": f"{G}x{H}", "rows_per_gpu": G, "glyph": glyph,

@@ -182,7 +182,7 @@ struct Pipeline::Impl {
         hg.state_row0 = std::max(0, r0 - halo);
         hg.state_rows = std::min(g.height, r1 + halo) - hg.state_row0;
 
-        s = detail::hip_status(pcr_hip_engine_create(&engine, &hg, 0, stream));
+        s = detail::hip_status(pcr_hip_engine_create(&engine, &hg, cfg.gpu_pool_size_bytes, stream));   // arena pre-sized at create, like the reference's MemoryPool
         if (!s.ok()) return s;
         s = detail::hip_status(pcr_hip_engine_set_path(engine, cfg.scatter_path));
         if (!s.ok()) return s;
