@@ -96,6 +96,7 @@ struct Pipeline::Impl {
     std::vector<Output> outputs;
     std::vector<detail::Buffer> d_bands;     // finalized bands on the device (result_location == Host)
     std::unique_ptr<Grid> result;
+    bool finalized = false;                  // result() is null until the first finalize, as in the reference
     std::map<std::string, detail::Buffer> staging;   // device copies of host-resident arrays, grow-only
     int halo = 0;
     size_t collections = 0;
@@ -202,6 +203,7 @@ struct Pipeline::Impl {
             gr.view.d_max = static_cast<float*>(gr.planes[2].data());
             gr.view.d_min = static_cast<float*>(gr.planes[3].data());
         }
+        if (!outputs.empty() && !(s = allocate_result()).ok()) return s;
         return detail::hip_status(pcr_hip_stream_synchronize(stream));
     }
 
@@ -370,7 +372,9 @@ struct Pipeline::Impl {
         return Status::success();
     }
 
-    Status finalize() {
+    // The result grid (and, for a host-resident result, its device-side band buffers) is allocated
+    // once, at create: finalize only launches kernels.
+    Status allocate_result() {
         const int rows = own_rows();
         const int W = hg.width;
         std::vector<BandDesc> bands;
@@ -381,23 +385,31 @@ struct Pipeline::Impl {
             b.is_state = false;
             bands.push_back(b);
         }
-        if (bands.empty() || rows <= 0) {
-            result.reset();
-            return bands.empty() ? Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid")
-                                 : Status::success();
+        if (bands.empty()) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
+        if (rows <= 0) { result.reset(); return Status::success(); }
+        const bool on_device = cfg.result_location == MemoryLocation::Device;
+        result = on_device ? Grid::create(W, rows, bands, MemoryLocation::Device)
+                           : Grid::create_host_page_locked(W, rows, bands);
+        if (!result) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
+        if (!on_device) {
+            d_bands.resize(outputs.size());
+            for (auto& b : d_bands) {
+                Status s = b.allocate((size_t)rows * W * sizeof(float), MemoryLocation::Device);
+                if (!s.ok()) return s;
+            }
         }
+        return Status::success();
+    }
+
+    Status finalize() {
+        const int rows = own_rows();
+        const int W = hg.width;
+        if (outputs.empty()) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
+        if (rows <= 0) return Status::success();
         const bool on_device = cfg.result_location == MemoryLocation::Device;
         if (!result) {
-            result = on_device ? Grid::create(W, rows, bands, MemoryLocation::Device)
-                               : Grid::create_host_page_locked(W, rows, bands);
-            if (!result) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
-            if (!on_device) {
-                d_bands.resize(outputs.size());
-                for (auto& b : d_bands) {
-                    Status s = b.allocate((size_t)rows * W * sizeof(float), MemoryLocation::Device);
-                    if (!s.ok()) return s;
-                }
-            }
+            Status as = allocate_result();
+            if (!as.ok()) return as;
         }
         uint32_t* d_touched = nullptr;
         Status s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, nullptr, nullptr));
@@ -433,6 +445,7 @@ struct Pipeline::Impl {
         }
         s = detail::hip_status(pcr_hip_stream_synchronize(stream));
         if (!s.ok()) return s;
+        finalized = true;
         if (!cfg.output_path.empty())
             return Status::error(StatusCode::NotImplemented,
                 "pipeline: output_path is set but GeoTIFF writing is not part of this build "
@@ -653,7 +666,7 @@ Status Pipeline::run(const std::vector<const PointCloud*>& clouds) {
 }
 
 void Pipeline::set_progress_callback(ProgressCallback cb) { impl_->callback = std::move(cb); }
-const Grid* Pipeline::result() const { return impl_->result.get(); }
+const Grid* Pipeline::result() const { return impl_->finalized ? impl_->result.get() : nullptr; }
 ProgressInfo Pipeline::stats() const { return impl_->stats(); }
 
 int Pipeline::halo_rows() const { return impl_->halo; }
