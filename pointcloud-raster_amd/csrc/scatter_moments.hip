@@ -26,6 +26,7 @@
 #include "engine.hpp"
 #include "glyph_device.hpp"
 
+#include <type_traits>
 #include <vector>
 
 using namespace pcrhip;
@@ -330,125 +331,278 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 }
 
 // ---- convolutions ---------------------------------------------------------------------------------------
+// Both passes keep 16 consecutive outputs per lane in registers and slide the (2r+1)-tap window over
+// 16 + 2r sources; a source feeds up to 16 fused multiply-adds, taps are wave-uniform scalar operands
+// (zero-padded tables, s_load).  Sources come from LDS so that neighbouring output blocks share them
+// instead of re-reading L2 (the column pass was L2-bound at 7x read amplification without it).
+// Output group g (4 outputs) only meets non-zero taps for source steps mm in [4g, 4g + 2r + 3]: the
+// other (zero-tap) steps are skipped with a scalar branch.
+// One step = 4 consecutive sources v0..v3 against the 20 taps T(0..19) = tw[-3..16] of the step's window:
+// output j gains T(j + 3 - u) * v_u.  The FMAs are issued as packed pairs (v_pk_fma_f32) whose tap operands
+// are scalar register pairs; a pair must start at an even register, which holds for outputs (j, j+1), j even,
+// only against the odd sources -- so the even sources accumulate into a second file B shifted by one output
+// (B[i] = output i - 1; its two end entries are never read), and the two files are added at the end.
+// Every step fetches its 20 taps with two scalar loads (the tables sit in the scalar cache); other waves of
+// the SIMD cover that latency.  GM = output groups (4 outputs each) that can meet a non-zero tap.
+typedef float pcr_f2 __attribute__((ext_vector_type(2)));
+typedef pcr_f2 pcr_f2_u __attribute__((aligned(4)));          // a tap pair at any float offset
+
+struct ConvAcc {
+    pcr_f2 a[8];       // a[p] = outputs (2p, 2p + 1), fed by the odd sources
+    pcr_f2 b[9];       // b[p] = outputs (2p - 1, 2p), fed by the even sources; b[0].x and b[8].y are never read
+};
+
+__device__ __forceinline__ void conv_clear(ConvAcc& c) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) c.a[p] = pcr_f2{0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 9; ++p) c.b[p] = pcr_f2{0.f, 0.f};
+}
+
+__device__ __forceinline__ float conv_out(const ConvAcc& c, int j) {
+    return (j & 1) ? c.a[j >> 1].y + c.b[(j >> 1) + 1].x : c.a[j >> 1].x + c.b[j >> 1].y;
+}
+
+// t[i] = taps (T(2i), T(2i+1)), T(0..19) = tw[-3..16]
+template <unsigned GM>
+__device__ __forceinline__ void conv_step(ConvAcc& c, const pcr_f2 (&t)[10], float v0, float v1, float v2, float v3) {
+    const pcr_f2 s0{v0, v0}, s1{v1, v1}, s2{v2, v2}, s3{v3, v3};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {                      // outputs 2p, 2p + 1
+        if (!(GM & (1u << (p / 2)))) continue;
+        c.a[p] = __builtin_elementwise_fma(t[p + 1], s1, c.a[p]);
+        c.a[p] = __builtin_elementwise_fma(t[p], s3, c.a[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {                      // outputs 2p - 1, 2p
+        const bool on = (p >= 1 && (GM & (1u << ((2 * p - 1) / 4)))) || (p <= 7 && (GM & (1u << ((2 * p) / 4))));
+        if (!on) continue;
+        c.b[p] = __builtin_elementwise_fma(t[p + 1], s0, c.b[p]);
+        c.b[p] = __builtin_elementwise_fma(t[p], s2, c.b[p]);
+    }
+}
+
+// The whole sweep of one lane over its 16 + 2r sources.  src(c) yields source c (c = 0 is r sources before
+// output 0); tap of output j for source c: tbase[j - c].  Output group gq meets non-zero taps only for steps
+// mm in [4 gq, 4 gq + 2r + 3]: three ramp-up and three ramp-down steps run with fewer groups.
+template <typename Src>
+__device__ __forceinline__ void conv_sweep(ConvAcc& c, int r, const float* __restrict__ tbase, Src src) {
+    auto step = [&](auto gm, int mm) {
+        pcr_f2 t[10];
+        const pcr_f2_u* __restrict__ tw = reinterpret_cast<const pcr_f2_u*>(tbase - mm - 3);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) t[i] = tw[i];
+        conv_step<decltype(gm)::value>(c, t, src(mm), src(mm + 1), src(mm + 2), src(mm + 3));
+    };
+    using std::integral_constant;
+    // r >= 6 (make_plan): the three ramps and the steady range do not overlap
+    const int steady_hi = (2 * r + 3) & ~3;             // all four groups inside for mm in [12, steady_hi]
+    step(integral_constant<unsigned, 1>{}, 0);
+    step(integral_constant<unsigned, 3>{}, 4);
+    step(integral_constant<unsigned, 7>{}, 8);
+    // walked downwards: the tap pointer then climbs by 4 per step and every scalar load is pointer + immediate
+    for (int mm = steady_hi; mm >= 12; mm -= 4) step(integral_constant<unsigned, 15>{}, mm);
+    step(integral_constant<unsigned, 14>{}, steady_hi + 4);
+    step(integral_constant<unsigned, 12>{}, steady_hi + 8);
+    if (steady_hi + 12 < 16 + 2 * r) step(integral_constant<unsigned, 8>{}, steady_hi + 12);
+}
+
 // Column pass: U_k[y][x] = sum_{l <= K-k} sum_dy B_l(dy) M_kl[y - dy][x]; sources stay inside the output
-// row's reference tile and the state window.  One lane per column, 16 consecutive output rows per
-// wave in registers, taps as wave-uniform (scalar) loads from the zero-padded tables.
+// row's reference tile and the state window.  A workgroup owns 64 columns x 64 output rows (one lane per
+// column, 16 rows per wave) and stages the 64 + 2r source rows of one moment plane at a time in LDS.
+// NPF > 0: every thread keeps its NPF rows of the NEXT plane in flight (registers) behind the sweep of
+// the current one, so that HBM/L2 latency is paid once per workgroup, not once per plane; NPF == 0 is
+// the plain version for windows too tall for that.
+template <int NPF>
 __global__ void __launch_bounds__(256)
 k_conv_col(GridDev g, int K, int r, int yblocks_per_tile, const float* __restrict__ taps_y,
            const float* __restrict__ mom, int64_t plane_stride, float* __restrict__ u_out) {
-#pragma clang fp contract(fast)      // dense tap FMAs: fused multiply-add is both faster and more accurate here
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float lds_f[];                   // [64 + 2r + 4][64]
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane makes it an SGPR so that the taps below are
+    // fetched with scalar loads and feed the FMAs as scalar operands
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int x = blockIdx.x * 64 + lane;
     const int k = blockIdx.z;
     const int trow = blockIdx.y / yblocks_per_tile, yb = blockIdx.y - trow * yblocks_per_tile;
     // reference tile rows, in window coordinates
     const int t_lo = max(trow * g.th - g.st_r0, 0), t_hi = min(min((trow + 1) * g.th, g.H) - g.st_r0, g.st_rows);
-    // wave-uniform by construction; readfirstlane makes it an SGPR so that the taps below are
-    // fetched with scalar loads and feed the FMAs as scalar operands
-    const int y0 = __builtin_amdgcn_readfirstlane(t_lo + yb * 64 + wave * 16);
-    if (y0 >= t_hi) return;
+    const int Y0 = t_lo + yb * 64;
+    if (Y0 >= t_hi) return;                            // whole workgroup
+    const int nsrc = 64 + 2 * r, nalloc = nsrc + 4;    // LDS row s <-> window row Y0 - r + s; 4 zero rows of slack
     const int tap_w = 2 * r + 1 + 2 * kPad;
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    ConvAcc acc;
+    conv_clear(acc);
     // pair index of (k, 0): sum_{i<k} (K + 1 - i)
     int p0 = 0;
     for (int i = 0; i < k; ++i) p0 += K + 1 - i;
-    const int yi_lo = max(y0 - r, t_lo), yi_hi = min(y0 + 15 + r, t_hi - 1);
     const bool xin = x < g.W;
     const int xc = xin ? x : 0;
-    for (int l = 0; l <= K - k; ++l) {
-        const float* __restrict__ plane = mom + (int64_t)(p0 + l) * plane_stride + xc;
-        const float* __restrict__ tl = taps_y + l * tap_w;
-        int yi = yi_lo;
-        for (; yi + 3 <= yi_hi; yi += 4) {                 // four source rows in flight per step
-            const float v0 = plane[(int64_t)(yi + 0) * g.W], v1 = plane[(int64_t)(yi + 1) * g.W];
-            const float v2 = plane[(int64_t)(yi + 2) * g.W], v3 = plane[(int64_t)(yi + 3) * g.W];
-            const float* __restrict__ tw = tl + (y0 - yi + r + kPad);   // tap of output j for row yi+u: tw[j - u]
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                acc[j] += tw[j] * v0 + tw[j - 1] * v1 + tw[j - 2] * v2 + tw[j - 3] * v3;
-        }
-        for (; yi <= yi_hi; ++yi) {
-            const float v0 = plane[(int64_t)yi * g.W];
-            const float* __restrict__ tw = tl + (y0 - yi + r + kPad);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * v0;
-        }
-    }
-    if (!xin) return;
-    float* uo = u_out + (int64_t)k * plane_stride;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (y0 + j < t_hi) uo[(int64_t)(y0 + j) * g.W + x] = acc[j];
-}
+    const bool active = Y0 + wave * 16 < t_hi;
+    const float* tb = lds_f + wave * 16 * 64 + lane;
 
-// Row pass + accumulate: out[y][x] += sum_k sum_dx A_k(dx) U_k[y][x - dx], sources inside the output
-// column's reference tile.  The U_k tile goes through LDS (odd row stride) so that one lane owns one
-// row and slides 16 outputs along x; results return through LDS for a coalesced read-modify-write.
-__global__ void __launch_bounds__(256)
-k_conv_row_accum(GridDev g, int K, int r, int xblocks_per_tile, const float* __restrict__ taps_x,
-                 const float* __restrict__ u_in, int64_t plane_stride, float* __restrict__ out_plane) {
-#pragma clang fp contract(fast)
-    extern __shared__ float lds_f[];
-    const int tcol = blockIdx.x / xblocks_per_tile, xb = blockIdx.x - tcol * xblocks_per_tile;
-    const int t_lo = tcol * g.tw, t_hi = min((tcol + 1) * g.tw, g.W);
-    const int bx0 = t_lo + xb * 64;
-    if (bx0 >= t_hi) return;
-    const int by0 = blockIdx.y * 64;
-    const int span = 64 + 2 * r;                       // source columns [bx0 - r, bx0 + 64 + r)
-    const int stride = span | 1;                       // odd: lanes (rows) hit different banks
-    float* tile = lds_f;                               // [64][stride]
-    float* outt = lds_f + 64 * stride;                 // [64][65]
-    const int row = threadIdx.x & 63;
-    const int xq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // the wave index: scalar
-    const int x0 = bx0 + xq * 16;
-    const int tap_w = 2 * r + 1 + 2 * kPad;
-    float acc[16];
+    // Staging: row pointers are wave-uniform (scalar), the lane only adds its column.  Lanes right of the
+    // grid read column 0 and carry throw-away results, so no load is predicated per lane.
+    float pre[NPF > 0 ? NPF : 1];
+    // (the wave index goes through an opaque asm so that the per-row scalar state -- pointers, validity -- is
+    //  recomputed at each use instead of being hoisted out of the plane loop as ~100 live scalars)
+    auto issue = [&](int l) {                          // wave w owns rows w, w+4, ...
+        int w = wave;
+        asm volatile("" : "+s"(w));
+        const int u_lo = max(0, (t_lo - (Y0 - r) - w + 3) >> 2);                 // rows of the reference tile ...
+        const int u_hi = (min(t_hi - (Y0 - r), nsrc) - w + 3) >> 2;              // ... and of the window: u in [u_lo, u_hi)
+        const float* __restrict__ rowp = mom + (int64_t)(p0 + l) * plane_stride + (int64_t)(Y0 - r + w) * g.W;
+        const int64_t step4 = (int64_t)4 * g.W;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    const int xi_lo = max(x0 - r, t_lo), xi_hi = min(x0 + 15 + r, t_hi - 1);
-    for (int k = 0; k <= K; ++k) {
-        const float* uk = u_in + (int64_t)k * plane_stride;
-        __syncthreads();
-        // wave w loads rows w, w+4, ...; a lane walks the row in steps of 64 columns (coalesced, no division)
-        for (int ry = xq; ry < 64; ry += 4) {
-            const int gy = by0 + ry;
-            const float* urow = uk + (int64_t)gy * g.W;
-            for (int cx = threadIdx.x & 63; cx < span; cx += 64) {
-                const int gx = bx0 - r + cx;
-                float val = 0.f;
-                if (gx >= t_lo && gx < t_hi && gy < g.st_rows) val = urow[gx];
-                tile[ry * stride + cx] = val;
+        for (int u = 0; u < NPF; ++u) {
+            pre[u] = (u >= u_lo && u < u_hi) ? rowp[xc] : 0.f;
+            rowp += step4;
+        }
+    };
+    if (NPF > 0) issue(0);
+    for (int l = 0; l <= K - k; ++l) {
+        __syncthreads();                               // the previous plane's readers are done
+        if (NPF > 0) {
+            int w = wave;
+            asm volatile("" : "+s"(w));
+            const int u_end = (nalloc - w + 3) >> 2;
+            float* dst = lds_f + w * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < NPF; ++u)
+                if (u < u_end) dst[u * 256] = pre[u];
+        } else {
+            const float* __restrict__ plane = mom + (int64_t)(p0 + l) * plane_stride;
+            for (int s0 = wave; s0 < nalloc; s0 += 32) {
+                float vals[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sr = s0 + 4 * u, yy = Y0 - r + sr;
+                    const float* __restrict__ rowp = plane + (int64_t)yy * g.W;
+                    vals[u] = (sr < nsrc && yy >= t_lo && yy < t_hi) ? rowp[xc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + 4 * u < nalloc) lds_f[(s0 + 4 * u) * 64 + lane] = vals[u];
             }
         }
         __syncthreads();
-        const float* __restrict__ tk = taps_x + k * tap_w;
-        const float* trow = tile + row * stride - (bx0 - r);
-        int xi = xi_lo;
-        for (; xi + 3 <= xi_hi; xi += 4) {
-            const float v0 = trow[xi], v1 = trow[xi + 1], v2 = trow[xi + 2], v3 = trow[xi + 3];
-            const float* __restrict__ tw = tk + (x0 - xi + r + kPad);
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                acc[j] += tw[j] * v0 + tw[j - 1] * v1 + tw[j - 2] * v2 + tw[j - 3] * v3;
-        }
-        for (; xi <= xi_hi; ++xi) {
-            const float v0 = trow[xi];
-            const float* __restrict__ tw = tk + (x0 - xi + r + kPad);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] += tw[j] * v0;
-        }
+        if (NPF > 0 && l < K - k) issue(l + 1);
+        const float* __restrict__ tl = taps_y + l * tap_w + kPad + 2 * r;      // wave-uniform
+        conv_sweep(acc, r, tl, [&](int c) { return tb[c * 64]; });       // source c = LDS row 16 * wave + c
     }
+    if (!xin || !active) return;
+    float* uo = u_out + (int64_t)k * plane_stride;
+    const int y0 = Y0 + wave * 16;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) outt[row * 65 + xq * 16 + j] = acc[j];
-    __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        int ry = i >> 6, cx = i & 63;
-        int gx = bx0 + cx, gy = by0 + ry;
-        if (gx < t_hi && gy < g.st_rows) {
-            float a = outt[ry * 65 + cx];
-            if (a != 0.f) out_plane[(int64_t)gy * g.W + gx] += a;
+    for (int j = 0; j < 16; ++j)
+        if (y0 + j < t_hi) uo[(int64_t)(y0 + j) * g.W + x] = conv_out(acc, j);
+}
+
+// Row pass + accumulate: out[y][x] += sum_k sum_dx A_k(dx) U_k[y][x - dx], sources inside the output
+// column's reference tile.  One lane owns 16 consecutive outputs of a row; a wave owns RW rows x 16*LPR
+// columns (LPR lanes per row) and keeps its source rows in a wave-private LDS strip -- no workgroup
+// barriers.  Logical column c of a strip lives at c + c/16: lanes 16 columns apart then hit different
+// banks (row strides are chosen = 64/RW mod 64 so that the RW rows of a wave do not collide either).
+// NPR > 0: the NPR x 64 columns of each row of the NEXT plane are kept in flight in registers behind
+// the sweep of the current one; NPR == 0: plain version for wider windows.
+template <int LPR_SHIFT, int NPR>
+__global__ void __launch_bounds__(256)
+k_conv_row_accum(GridDev g, int K, int r, int xunits_per_tile, int rs, const float* __restrict__ taps_x,
+                 const float* __restrict__ u_in, int64_t plane_stride, float* __restrict__ out_plane) {
+    constexpr int LPR = 1 << LPR_SHIFT, RW = 64 / LPR, COLS = 16 * LPR;
+    extern __shared__ float lds_f[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tcol = blockIdx.x / xunits_per_tile, xu = blockIdx.x - tcol * xunits_per_tile;
+    const int t_lo = tcol * g.tw, t_hi = min((tcol + 1) * g.tw, g.W);
+    const int X0 = t_lo + xu * COLS;
+    const int Y0 = (blockIdx.y * 4 + wave) * RW;
+    if (X0 >= t_hi || Y0 >= g.st_rows) return;        // wave-uniform; this kernel has no workgroup barrier
+    const int span = COLS + 2 * r;                     // source columns [X0 - r, X0 + COLS + r)
+    const int spanp = span + 4;                        // + zero slack read by the last step
+    float* wt = lds_f + wave * (RW * rs);
+    const int rr = lane >> LPR_SHIFT, xb = lane & (LPR - 1);
+    const float* lb = wt + rr * rs + 17 * xb;
+    const int tap_w = 2 * r + 1 + 2 * kPad;
+    ConvAcc acc;
+    conv_clear(acc);
+
+    constexpr int NP = NPR > 0 ? RW * NPR : 1;
+    float pre[NP];
+    // valid source columns of the strip, as strip-relative c in [c_lo, c_hi)
+    const int c_lo = max(t_lo - (X0 - r), 0), c_hi = min(t_hi - (X0 - r), span);
+    // (lane goes through an opaque asm in the staging code so that per-load masks and offsets are recomputed
+    //  where used instead of being hoisted out of the plane loop as dozens of live scalar pairs)
+    auto issue = [&](int k) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const float* uk = u_in + (int64_t)k * plane_stride + (X0 - r);
+#pragma unroll
+        for (int row = 0; row < RW; ++row) {
+            const int gy = Y0 + row;
+            const float* __restrict__ urow = uk + (int64_t)min(gy, g.st_rows - 1) * g.W;      // scalar
+            const unsigned width = gy < g.st_rows ? (unsigned)(c_hi - c_lo) : 0u;
+#pragma unroll
+            for (int u = 0; u < NPR; ++u) {
+                const int c = ln + 64 * u;
+                pre[row * (NPR > 0 ? NPR : 1) + u] = (unsigned)(c - c_lo) < width ? urow[c] : 0.f;
+            }
+        }
+    };
+    if (NPR > 0) issue(0);
+    for (int k = 0; k <= K; ++k) {
+        if (NPR > 0) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            float* wb = wt + ln + (ln >> 4);                  // column c = ln + 64u lives at c + c/16 = wb + 68u
+#pragma unroll
+            for (int row = 0; row < RW; ++row)
+#pragma unroll
+                for (int u = 0; u < NPR; ++u)
+                    if (ln + 64 * u < spanp) wb[row * rs + 68 * u] = pre[row * (NPR > 0 ? NPR : 1) + u];
+        } else {
+            const float* uk = u_in + (int64_t)k * plane_stride;
+            for (int row = 0; row < RW; ++row) {
+                const int gy = Y0 + row;
+                const float* urow = uk + (int64_t)min(gy, g.st_rows - 1) * g.W;
+                for (int c0 = lane; c0 < spanp; c0 += 512) {         // eight coalesced loads in flight
+                    float vals[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + 64 * u, gx = X0 - r + c;
+                        vals[u] = (c < span && gx >= t_lo && gx < t_hi && gy < g.st_rows) ? urow[gx] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + 64 * u;
+                        if (c < spanp) wt[row * rs + c + (c >> 4)] = vals[u];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (NPR > 0 && k < K) issue(k + 1);
+        const float* __restrict__ tk = taps_x + k * tap_w + kPad + 2 * r;
+        conv_sweep(acc, r, tk, [&](int c) { return lb[c + (c >> 4)]; });
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // results return through the strip for a coalesced read-modify-write
+    float* ob = wt + rr * rs + 17 * xb;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ob[j] = conv_out(acc, j);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int row = 0; row < RW; ++row) {
+        const int gy = Y0 + row;
+        if (gy >= g.st_rows) break;
+        for (int c = lane; c < COLS; c += 64) {
+            const int gx = X0 + c;
+            if (gx < t_hi) {
+                const float a = wt[row * rs + c + (c >> 4)];
+                if (a != 0.f) out_plane[(int64_t)gy * g.W + gx] += a;
+            }
         }
     }
 }
@@ -502,7 +656,7 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     if (gl.def_rotation != 0.0f) return false;                       // cos == 1, sin == 0 exactly
     const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
     const float R = std::min(3.0f * std::max(sx, sy), gl.max_radius);
-    if (!(sx > 0.0f) || sy == 0.0f || !(R >= 1.0f) || R > 200.0f) return false;
+    if (!(sx > 0.0f) || sy == 0.0f || !(R > 5.0f) || R > 200.0f) return false;   // r >= 6: smaller footprints are cheap to splat
     const int r = (int)std::ceil(R);
     const double asy = std::fabs((double)sy), sx2 = (double)sx * sx, sy2 = asy * asy;
     // the reference drops weights < 1e-6 (glyph_kernels.cu:166): must never trigger inside the window
@@ -659,25 +813,59 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         else dispatch_moments<3>(e, p, d_rec, d_start, mom_v, mom_w, cells);
     }
     // convolutions, per plane kind
-    const int yblocks = (std::min(g.th, g.H) + 63) / 64, xblocks = (std::min(g.tw, g.W) + 63) / 64;
+    const int yblocks = (std::min(g.th, g.H) + 63) / 64;
     const int tiles_y = g.tiles_y, tiles_x = g.tiles_x;
-    const int span = 64 + 2 * p.r;
-    const size_t row_lds = ((size_t)64 * (span | 1) + 64 * 65) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_row_accum),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+    const size_t col_lds = (size_t)(64 + 2 * p.r + 4) * 64 * sizeof(float);
+    const int col_rows_per_wave = (64 + 2 * p.r + 4 + 3) / 4;
+    const dim3 col_grid((g.W + 63) / 64, tiles_y * yblocks, p.K + 1);
+    auto launch_col = [&](auto kernel, const float* src) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
+        hipLaunchKernelGGL(kernel, col_grid, dim3(256), col_lds, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
+    };
+    // row pass shape: the strip width (1024 / 256 / 64 columns) that wastes the fewest lanes on this tile width
+    const int eff_tw = std::min(g.tw, g.W);
+    int lpr_shift = 6;
+    double best = -1.0;
+    for (int sh : {6, 4, 2}) {
+        const int cols = 16 << sh;
+        const double util = (double)eff_tw / ((double)((eff_tw + cols - 1) / cols) * cols);
+        if (util > best + 0.05) { best = util; lpr_shift = sh; }
+    }
+    const int rw = 64 >> lpr_shift, cols = 16 << lpr_shift;
+    const int spanp = cols + 2 * p.r + 4;
+    const int need = spanp + (spanp >> 4) + 1, bank_off = (64 / rw) % 64;
+    const int rs = ((need - bank_off + 63) / 64) * 64 + bank_off;      // rs >= need, rs = 64/RW (mod 64)
+    const size_t row_lds = (size_t)4 * rw * rs * sizeof(float);
+    const int xunits = (eff_tw + cols - 1) / cols;
+    const int npr_need = (spanp + 63) / 64;                             // 64-column loads per row of a strip
+    const dim3 row_grid(tiles_x * xunits, ((g.st_rows + rw - 1) / rw + 3) / 4);
+    auto launch_row = [&](auto kernel, const float* src, float* outp) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+        hipLaunchKernelGGL(kernel, row_grid, dim3(256), row_lds, e->stream, g, p.K, p.r, xunits, rs, taps_x, src, cells, outp);
+    };
     for (int kind = 0; kind < 2; ++kind) {
         const float* mom = kind == 0 ? mom_v : mom_w;
         float* outp = kind == 0 ? pl.sum : pl.wgt;
         if (!mom) continue;
         {
             ScopedKernelTimer t(e, "k_conv_col");
-            hipLaunchKernelGGL(k_conv_col, dim3((g.W + 63) / 64, tiles_y * yblocks, p.K + 1), dim3(256), 0, e->stream,
-                               g, p.K, p.r, yblocks, taps_y, mom, cells, d_u);
+            if (col_rows_per_wave <= 24) launch_col(&k_conv_col<24>, mom);
+            else if (col_rows_per_wave <= 32) launch_col(&k_conv_col<32>, mom);
+            else if (col_rows_per_wave <= 48) launch_col(&k_conv_col<48>, mom);
+            else launch_col(&k_conv_col<0>, mom);
         }
         {
             ScopedKernelTimer t(e, "k_conv_row_accum");
-            hipLaunchKernelGGL(k_conv_row_accum, dim3(tiles_x * xblocks, (g.st_rows + 63) / 64), dim3(256), row_lds,
-                               e->stream, g, p.K, p.r, xblocks, taps_x, d_u, cells, outp);
+            if (lpr_shift == 6) {
+                if (npr_need <= 20) launch_row(&k_conv_row_accum<6, 20>, d_u, outp);
+                else launch_row(&k_conv_row_accum<6, 0>, d_u, outp);
+            } else if (lpr_shift == 4) {
+                if (npr_need <= 6) launch_row(&k_conv_row_accum<4, 6>, d_u, outp);
+                else launch_row(&k_conv_row_accum<4, 0>, d_u, outp);
+            } else {
+                if (npr_need <= 3) launch_row(&k_conv_row_accum<2, 3>, d_u, outp);
+                else launch_row(&k_conv_row_accum<2, 0>, d_u, outp);
+            }
         }
     }
     {

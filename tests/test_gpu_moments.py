@@ -42,6 +42,10 @@ CASES = [
     dict(name="s4_r12", G=(192, 128), sigma=(4.0, 4.0), maxr=12.0, n=8000, tile=(4096, 4096)),
     dict(name="s6_aniso", G=(160, 160), sigma=(6.0, 5.0), maxr=32.0, n=5000, tile=(4096, 4096)),
     dict(name="s8_tiles", G=(192, 160), sigma=(8.0, 8.0), maxr=20.0, n=6000, tile=(64, 48)),      # taps stop at tile edges (Q4)
+    dict(name="s8_w1024", G=(1024, 48), sigma=(8.0, 8.0), maxr=24.0, n=6000, tile=(4096, 4096)),       # 1024-column row strips
+    dict(name="s6_w2000", G=(2000, 40), sigma=(6.0, 6.0), maxr=18.0, n=6000, tile=(4096, 4096)),       # two strips, ragged end
+    dict(name="s8_tiles300", G=(700, 100), sigma=(8.0, 8.0), maxr=24.0, n=6000, tile=(300, 48)),        # ragged reference tiles
+    dict(name="s4_r6", G=(128, 96), sigma=(4.0, 4.0), maxr=6.0, n=4000, tile=(4096, 4096)),             # smallest window the path takes
     dict(name="s5_halfcell", G=(256, 128), sigma=(3.0, 3.0), maxr=32.0, n=6000, tile=(4096, 4096), cell=(0.5, -0.5)),
 ]
 
