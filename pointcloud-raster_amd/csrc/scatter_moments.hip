@@ -7,8 +7,8 @@
 //                               = sum_k A_k(d) m_k(s'),   A_k(d) = exp(-u^2/2 sigma^2) (u/sigma^2)^k / k!,
 //                                                         m_k(s') = s'^k exp(-s'^2/2 sigma^2)
 //
-// |u s'/sigma^2| <= (r + 1/2)/(2 sigma^2) is small for large sigma, so a total order K of 5 (sigma=16)
-// to 9 (sigma=4) reproduces the reference weights to ~1e-7 (tests, numpy prototype).  Then
+// |u s'/sigma^2| <= (r + 1/2)/(2 sigma^2) is small for large sigma, so a total order K of 4 (sigma=16)
+// to 7 (sigma=4) reproduces every weight to <= 1e-5 relative (bound in make_plan; measured in tests).  Then
 //
 //   splat = sum_{k+l<=K} (A_k (x) B_l) * M_kl ,   M_kl[cell] = sum_{points centred in cell} v m_k(s'x) n_l(s'y)
 //
@@ -63,27 +63,55 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
     unsigned my_valid = 0;
-    for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
-        uint64_t i = base + k;
-        if (i >= n) break;
-        double wx = x[i], wy = y[i];
+    auto handle = [&](uint64_t i, double wx, double wy, float val) -> unsigned {
         PointGeom pg = point_geom(g, wx, wy);
-        unsigned key = 0xFFFFFFFFu;
-        if (pg.valid && point_kept(g, i)) {
-            ++my_valid;
-            touch_tile(g, touched, pg.row, pg.col);
-            int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);
-            if (finite_f(v[i]) && icx == pg.col && icy == pg.row) {
-                int sr = pg.row - g.st_r0;
-                int bx = pg.col / b.tile_w, by = sr / b.tile_h;
-                int bin = by * b.bins_x + bx;
-                key = ((unsigned)bin << kLcellBits) | (unsigned)((sr - by * b.tile_h) * b.tile_w + (pg.col - bx * b.tile_w));
-                atomicAdd(&lds_hist[bin], 1u);
-            } else {
-                fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;           // rare: painted directly afterwards
+        if (!(pg.valid && point_kept(g, i))) return 0xFFFFFFFFu;
+        ++my_valid;
+        touch_tile(g, touched, pg.row, pg.col);
+        int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);
+        if (finite_f(val) && icx == pg.col && icy == pg.row) {
+            int sr = pg.row - g.st_r0;
+            int bx = pg.col / b.tile_w, by = sr / b.tile_h;
+            int bin = by * b.bins_x + bx;
+            atomicAdd(&lds_hist[bin], 1u);
+            return ((unsigned)bin << kLcellBits) | (unsigned)((sr - by * b.tile_h) * b.tile_w + (pg.col - bx * b.tile_w));
+        }
+        fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;                   // rare: painted directly afterwards
+        return 0xFFFFFFFFu;
+    };
+    const bool full = base + (uint64_t)b.chunk <= n &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(v) & 7) == 0;
+    if (full) {
+        // two points per lane and load, four loads per array in flight before any math
+        const double2* x2 = reinterpret_cast<const double2*>(x + base);
+        const double2* y2 = reinterpret_cast<const double2*>(y + base);
+        const float2* v2 = reinterpret_cast<const float2*>(v + base);
+        uint2* k2 = reinterpret_cast<uint2*>(keys + base);
+        const int pairs = b.chunk >> 1;                          // chunk = 8192: exactly one trip
+        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kThreads) {
+            double2 xs[4], ys[4];
+            float2 vs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xs[u] = x2[p0 + u * kThreads];
+                ys[u] = y2[p0 + u * kThreads];
+                vs[u] = v2[p0 + u * kThreads];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = base + 2ull * (p0 + u * kThreads);
+                unsigned ka = handle(i, xs[u].x, ys[u].x, vs[u].x);
+                unsigned kb = handle(i + 1, xs[u].y, ys[u].y, vs[u].y);
+                k2[p0 + u * kThreads] = make_uint2(ka, kb);
             }
         }
-        keys[i] = key;
+    } else {
+        for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
+            uint64_t i = base + k;
+            if (i >= n) break;
+            keys[i] = handle(i, x[i], y[i], v[i]);
+        }
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
     __syncthreads();
@@ -140,18 +168,30 @@ k_mom_scatter(GridDev g, BinGeom b, const unsigned* __restrict__ keys, const dou
     const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
     unsigned key[kScatterPer], rank[kScatterPer];
     float val[kScatterPer], sx[kScatterPer], sy[kScatterPer];
+    {
+        // every load of the chunk is issued before the first use (a point that will be dropped is read too)
+        double wx[kScatterPer], wy[kScatterPer];
 #pragma unroll
-    for (int k = 0; k < kScatterPer; ++k) {
-        uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
-        key[k] = i < n ? keys[i] : 0xFFFFFFFFu;
-        rank[k] = 0;
-        val[k] = sx[k] = sy[k] = 0.f;
-        if (key[k] != 0xFFFFFFFFu) {
-            double fcx = (x[i] - g.min_x) * g.inv_csx, fcy = (y[i] - g.max_y) * g.inv_csy;
-            sx[k] = (float)(fcx - floor(fcx)) - 0.5f;        // the reference's f32 sub-cell offset, recentred
-            sy[k] = (float)(fcy - floor(fcy)) - 0.5f;
-            val[k] = v[i];
-            rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
+        for (int k = 0; k < kScatterPer; ++k) {
+            const uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+            const uint64_t ic = i < n ? i : n - 1;
+            key[k] = i < n ? keys[ic] : 0xFFFFFFFFu;
+            wx[k] = x[ic];
+            wy[k] = y[ic];
+            val[k] = v[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < kScatterPer; ++k) {
+            rank[k] = 0;
+            sx[k] = sy[k] = 0.f;
+            if (key[k] != 0xFFFFFFFFu) {
+                double fcx = (wx[k] - g.min_x) * g.inv_csx, fcy = (wy[k] - g.max_y) * g.inv_csy;
+                sx[k] = (float)(fcx - floor(fcx)) - 0.5f;        // the reference's f32 sub-cell offset, recentred
+                sy[k] = (float)(fcy - floor(fcy)) - 0.5f;
+                rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
+            } else {
+                val[k] = 0.f;
+            }
         }
     }
     __syncthreads();
@@ -301,11 +341,11 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
             // then fold them (otherwise every record costs one dependent L2/HBM latency)
             for (unsigned e = e0; e < e1; e += 4) {
                 const unsigned left = e1 - e;
-                const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+                const unsigned last = e1 - 1;                      // clamped, not predicated: plain global loads
                 const uint4 b0 = rec[idx[e]];
-                const uint4 b1 = left > 1 ? rec[idx[e + 1]] : zero;
-                const uint4 b2 = left > 2 ? rec[idx[e + 2]] : zero;
-                const uint4 b3 = left > 3 ? rec[idx[e + 3]] : zero;
+                const uint4 b1 = rec[idx[min(e + 1, last)]];
+                const uint4 b2 = rec[idx[min(e + 2, last)]];
+                const uint4 b3 = rec[idx[min(e + 3, last)]];
                 fold(b0);
                 if (left > 1) fold(b1);
                 if (left > 2) fold(b2);
@@ -662,13 +702,17 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     // the reference drops weights < 1e-6 (glyph_kernels.cu:166): must never trigger inside the window
     const double qmax = 0.5 * ((r + 1.0) * (r + 1.0) / sx2 + (r + 1.0) * (r + 1.0) / sy2);
     if (qmax > 13.5) return false;
-    // total order K: remainder of exp(t), t = |u s'/sigma^2| summed over both axes
+    // Total order K of the expansion of exp(a + b), |a| + |b| <= t (t = |u s'/sigma^2| summed over both axes):
+    // relative error of a weight <= e^t * sum_{n > K} t^n / n! <= e^t * t^(K+1)/(K+1)! / (1 - t/(K+2)).
+    // The bound is met only on the rim of the footprint (where the weight itself is ~1 % of the peak); K is
+    // the smallest order whose bound is <= 1e-5, a tenth of the 1e-4 tolerance every Gaussian path is tested to.
     const double t = (r + 0.5) * 0.5 / sx2 + (r + 0.5) * 0.5 / sy2;
     int K = 0;
     double term = t;                                                   // t^(K+1)/(K+1)!
-    while (term > 1e-7 && K < 32) { ++K; term *= t / (K + 1); }
+    auto bound = [&]() { return std::exp(t) * term / (1.0 - t / (K + 2)); };
+    while ((t >= K + 2 || bound() > 1e-5) && K < 32) { ++K; term *= t / (K + 1); }
     if (K > kMaxK) return false;
-    K = K <= 5 ? 5 : K <= 7 ? 7 : 9;                                   // instantiated orders
+    K = K <= 4 ? 4 : K <= 5 ? 5 : K <= 7 ? 7 : 9;                      // instantiated orders
     MomPlan p;
     p.K = K;
     p.P = (K + 1) * (K + 2) / 2;
@@ -712,7 +756,8 @@ void launch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const
 template <unsigned MASK>
 void dispatch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                       float* mom_v, float* mom_w, int64_t stride) {
-    if (p.K == 5) launch_moments<5, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+    if (p.K == 4) launch_moments<4, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 5) launch_moments<5, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
     else if (p.K == 7) launch_moments<7, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
     else launch_moments<9, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
 }
@@ -727,14 +772,13 @@ bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mas
     if (!make_plan(e->gd, gl, &p)) return false;
     if (e->stats.points_in >= (1ull << 32) - (1ull << 20)) return false;
     if (e->forced_path == 3) return true;
-    // worth it when painting footprints costs more than the point-count independent convolutions:
-    // ~1.5 ps per footprint cell-update (measured, LDS-tile splat) vs ~0.12 ps per cell x pair x tap
-    // (measured on MI355X, 4096^2: splat 1.5 ps per cell update; convolutions 0.16 ps per cell x pair x tap
-    //  for both plane kinds; moment passes 37 ps + 0.9 ps x pairs per point)
+    // worth it when painting footprints costs more than the point-count independent convolutions
+    // (measured on MI355X, 4096^2, 50 M points: LDS-tile splat ~1.5 ps per cell update; convolutions ~0.09 ps
+    //  per cell x pair x tap for both plane kinds; moment passes 37 ps + 0.75 ps x pairs per point)
     const double n = (double)e->stats.points_in;
     const double splat = n * (2.0 * p.r + 1) * (2.0 * p.r + 1) * 1.5e-12;
-    const double conv = (double)e->gd.W * e->gd.st_rows * p.P * (2.0 * p.r + 1) * 1.6e-13 +
-                        n * (37e-12 + 0.91e-12 * p.P);
+    const double conv = (double)e->gd.W * e->gd.st_rows * p.P * (2.0 * p.r + 1) * 0.9e-13 +
+                        n * (37e-12 + 0.75e-12 * p.P);
     return conv < splat;
 }
 
