@@ -3,6 +3,7 @@
 // scatter_direct.hip / scatter_binned.hip.
 #include "engine.hpp"
 
+#include <cstdlib>
 #include <mutex>
 #include <new>
 
@@ -99,6 +100,11 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
     e->grid = *g;
     e->gd = make_grid_dev(*g);
     e->stream = static_cast<hipStream_t>(s);
+    e->max_bins = kMaxBins;
+    if (const char* dbg = std::getenv("PCR_HIP_DEBUG_MAX_BINS")) {
+        const int v = std::atoi(dbg);
+        if (v >= 1 && v < kMaxBins) e->max_bins = v;
+    }
     hipError_t err = hipGetDevice(&e->device);
     hipDeviceProp_t prop;
     if (err == hipSuccess) err = hipGetDeviceProperties(&prop, e->device);

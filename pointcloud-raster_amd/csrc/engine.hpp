@@ -18,6 +18,8 @@ struct pcr_hip_engine {
     unsigned long long* d_counters = nullptr;  // [0] = valid points of the last scatter
 
     int forced_path = 0;                       // 0 auto, 1 direct, 2 binned, 3 moments (Gaussian only)
+    int max_bins = 0;                          // LDS tiles per binning pass (kMaxBins; PCR_HIP_DEBUG_MAX_BINS lowers it
+                                               // so that tests reach the row-band sweep on small grids)
     pcr_hip_scatter_stats stats{};
 
     // optional per-kernel event timing
@@ -59,7 +61,9 @@ struct BinGeom {
     int tile_w, tile_h;                 // interior of an LDS tile, cells (a bin owns these cells)
     int bins_x, bins_y, nbins;
     int chunk;                          // points per workgroup in the count / scatter passes
+    int row0, rows;                     // the band of state rows [row0, row0 + rows) the bins cover (window-relative)
 };
+constexpr int kMaxBands = 32;           // a grid with more LDS tiles than kMaxBins is swept in row bands
 struct BinItem {                        // one workgroup's share of a bin's records
     unsigned bin, first, count, shared; // shared != 0: the bin was split, merge with atomics
 };
@@ -72,10 +76,20 @@ struct BinBuffers {                     // device pointers into the engine's scr
 constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 12 B per bin <= 160 KB
 constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
 
-// Passes A (histogram + routing keys), scan, B (LDS-staged scatter).  index_records: record.y is
+// Rows per band so that a band's bins fit the binning passes (whole tile rows); 0 = cannot be banded.
+inline int band_rows_for(const GridDev& g, int tile_w, int tile_h, int max_bins) {
+    const int bins_x = (g.W + tile_w - 1) / tile_w;
+    const int bins_y = max_bins / bins_x;
+    if (bins_y < 1) return 0;
+    const int64_t rows = (int64_t)bins_y * tile_h;
+    return (int)(rows < g.st_rows ? rows : g.st_rows);
+}
+
+// Passes A (histogram + routing keys), scan, B (LDS-staged scatter) over the points that gd owns (for a band:
+// the engine's grid with the owned rows narrowed to the band).  index_records: record.y is
 // the point's index (glyph paths re-read x, y, v, channels by index) instead of its value.
 // extra_scratch bytes are reserved after the binning buffers and returned through *extra.
-int bin_points(pcr_hip_engine* e, const BinGeom& b, const double* x, const double* y, const float* v,
+int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
                uint64_t n, bool index_records, unsigned item_records, BinBuffers* out,
                size_t extra_scratch = 0, void** extra = nullptr);
 

@@ -38,7 +38,7 @@ __device__ __forceinline__ Routed route(const GridDev& g, const BinGeom& b, doub
     Routed r;
     r.valid = world_to_cell(g, wx, wy, r.col, r.row);
     r.valid = r.valid && r.row >= g.own_r0 && r.row < g.own_r1;
-    int sr = r.row - g.st_r0;
+    int sr = r.row - g.st_r0 - b.row0;                 // valid points lie inside the band: sr >= 0
     int bx = r.col / b.tile_w, by = sr / b.tile_h;
     r.bin = by * b.bins_x + bx;
     r.lcell = (unsigned)((sr - by * b.tile_h) * b.tile_w + (r.col - bx * b.tile_w));
@@ -273,14 +273,16 @@ inline int tile_cell_bytes(unsigned mask) {
 
 // LDS tile shape: 128 columns x as many rows (multiple of 8, <= 128) as fit ~150 KB of the CU's
 // 160 KB LDS at the per-cell footprint of the requested planes.
-inline BinGeom point_bin_geom(const GridDev& g, uint32_t mask) {
+inline BinGeom point_bin_geom(const GridDev& g, uint32_t mask, int row0, int rows) {
     BinGeom b;
     b.tile_w = 128;
     b.tile_h = std::min(128, (150 * 1024 / (std::max(tile_cell_bytes(mask), 4) * 128)) & ~7);
     b.bins_x = (g.W + b.tile_w - 1) / b.tile_w;
-    b.bins_y = (g.st_rows + b.tile_h - 1) / b.tile_h;
+    b.bins_y = (rows + b.tile_h - 1) / b.tile_h;
     b.nbins = b.bins_x * b.bins_y;
     b.chunk = b.nbins <= 2048 ? 16384 : 8192;
+    b.row0 = row0;
+    b.rows = rows;
     return b;
 }
 
@@ -330,8 +332,8 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
 
     // merge pass: tile -> HBM planes.  Exclusive owner => plain RMW; a split bin => atomics.
     const int bx = it.bin % b.bins_x, by = it.bin / b.bins_x;
-    const int c0 = bx * b.tile_w, r0 = by * b.tile_h;                 // r0 relative to the state window
-    const int w = min(b.tile_w, g.W - c0), h = min(b.tile_h, g.st_rows - r0);
+    const int c0 = bx * b.tile_w, r0 = b.row0 + by * b.tile_h;        // r0 relative to the state window
+    const int w = min(b.tile_w, g.W - c0), h = min(b.tile_h, b.row0 + b.rows - r0);
     const bool vec = !it.shared && (g.W % 4 == 0) && (w % 4 == 0) &&
                      ((((MASK & 1) ? reinterpret_cast<uintptr_t>(pl.sum) : 0) | ((MASK & 2) ? reinterpret_cast<uintptr_t>(pl.wgt) : 0) |
                        ((MASK & 4) ? reinterpret_cast<uintptr_t>(pl.mx) : 0) | ((MASK & 8) ? reinterpret_cast<uintptr_t>(pl.mn) : 0)) & 15) == 0;
@@ -389,11 +391,11 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
 }
 
 template <unsigned MASK>
-void launch_accum(pcr_hip_engine* e, const BinGeom& b, const PlanesDev& pl, const BinBuffers& bb) {
+void launch_accum(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const PlanesDev& pl, const BinBuffers& bb) {
     size_t lds = (size_t)b.tile_w * b.tile_h * tile_cell_bytes(MASK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_accum<MASK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, b, pl,
+    hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, b, pl,
                        bb.records, bb.items, bb.n_items);
 }
 
@@ -403,7 +405,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 namespace pcrhip {
 
-int bin_points(pcr_hip_engine* e, const BinGeom& b, const double* x, const double* y, const float* v,
+int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
                uint64_t n, bool index_records, unsigned item_records, BinBuffers* out,
                size_t extra_scratch, void** extra) {
     const int blocks = (int)((n + b.chunk - 1) / b.chunk);
@@ -432,7 +434,7 @@ int bin_points(pcr_hip_engine* e, const BinGeom& b, const double* x, const doubl
     {
         ScopedKernelTimer t(e, "k_bin_count");
         hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream,
-                           e->gd, b, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+                           gd, b, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
@@ -473,10 +475,21 @@ int bin_points(pcr_hip_engine* e, const BinGeom& b, const double* x, const doubl
     return PCR_HIP_OK;
 }
 
+// Bands of state rows, each with at most kMaxBins LDS tiles; every band is a full pass over the points
+// (routing keys are cheap: 5 ps per point and band) that only keeps the points of its rows.
+static int point_bands(const pcr_hip_engine* e, uint32_t mask, int* band_rows) {
+    const GridDev& g = e->gd;
+    const BinGeom b = point_bin_geom(g, mask, 0, g.st_rows);
+    *band_rows = band_rows_for(g, b.tile_w, b.tile_h, e->max_bins);
+    if (*band_rows <= 0) return 0;
+    return (g.st_rows + *band_rows - 1) / *band_rows;
+}
+
 bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask) {
     if (mask == 0 || (mask & ~15u)) return false;
-    BinGeom b = point_bin_geom(e->gd, mask);
-    if (b.nbins > kMaxBins) return false;
+    int band_rows = 0;
+    const int nbands = point_bands(e, mask, &band_rows);
+    if (nbands < 1 || nbands > kMaxBands) return false;
     // not worth the fixed cost of sweeping every tile for a handful of points
     uint64_t cells = (uint64_t)e->gd.W * e->gd.st_rows;
     if (e->forced_path != 2 && e->stats.points_in * 16 < cells) return false;
@@ -485,14 +498,25 @@ bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask) {
 
 int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n) {
-    const BinGeom b = point_bin_geom(e->gd, mask);
-    BinBuffers bb{};
-    int rc = bin_points(e, b, x, y, v, n, false, kPointItemRecords, &bb);
-    if (rc) return rc;
-    {
+    int band_rows = 0;
+    const int nbands = point_bands(e, mask, &band_rows);
+    if (nbands < 1) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: grid cannot be binned");
+    int total_bins = 0;
+    BinGeom b{};
+    for (int band = 0; band < nbands; ++band) {
+        const int row0 = band * band_rows, rows = std::min(band_rows, e->gd.st_rows - row0);
+        GridDev gd = e->gd;                                     // this band's points only
+        gd.own_r0 = std::max(e->gd.own_r0, e->gd.st_r0 + row0);
+        gd.own_r1 = std::min(e->gd.own_r1, e->gd.st_r0 + row0 + rows);
+        if (gd.own_r0 >= gd.own_r1) continue;
+        b = point_bin_geom(e->gd, mask, row0, rows);
+        total_bins += b.nbins;
+        BinBuffers bb{};
+        int rc = bin_points(e, gd, b, x, y, v, n, false, kPointItemRecords, &bb);
+        if (rc) return rc;
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {
-#define PCR_ACC(M) case M: launch_accum<M>(e, b, pl, bb); break;
+#define PCR_ACC(M) case M: launch_accum<M>(e, gd, b, pl, bb); break;
             PCR_ACC(1) PCR_ACC(2) PCR_ACC(3) PCR_ACC(4) PCR_ACC(5) PCR_ACC(6) PCR_ACC(7) PCR_ACC(8)
             PCR_ACC(9) PCR_ACC(10) PCR_ACC(11) PCR_ACC(12) PCR_ACC(13) PCR_ACC(14) PCR_ACC(15)
 #undef PCR_ACC
@@ -504,7 +528,7 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     e->stats.lds_tile_w = b.tile_w;
     e->stats.lds_tile_h = b.tile_h;
     e->stats.lds_apron = 0;
-    e->stats.num_bins = b.nbins;
+    e->stats.num_bins = total_bins;
     return PCR_HIP_OK;
 }
 

@@ -90,7 +90,7 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
 
     const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
     GaussLdsSink<MASK> sink{g, pl, t_s, t_w, bx * t.bins.tile_w - t.apron,
-                            g.st_r0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
+                            g.st_r0 + t.bins.row0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
 
     // each wave takes 64 of the item's points at a time: one lane prepares one point, then all
     // 64 lanes paint the points one after the other
@@ -155,7 +155,7 @@ k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __re
 
     const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
     LineLdsSink<MASK> sink{g, pl, t_s, t_c, bx * t.bins.tile_w - t.apron,
-                           g.st_r0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
+                           g.st_r0 + t.bins.row0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
     const uint2* rec = records + it.first;
     for (unsigned j = threadIdx.x; j < it.count; j += kThreads) {
         uint64_t i = rec[j].y;
@@ -201,16 +201,22 @@ int cell_bytes(int glyph_type, unsigned mask) {
     return ((mask & 1) ? 8 : 0) + ((mask & 2) ? 4 : 0);
 }
 
-bool glyph_tile(const GridDev& g, const GlyphDev& gl, unsigned mask, GlyphTile* out) {
+// Tile shape from the glyph's reach: the interior S x S is what the LDS leaves after an apron of `need`
+// cells on every side.  A grid with more such tiles than the binning passes take is swept in row bands
+// (band_rows rows each); only when even kMaxBands bands are not enough is S grown at the apron's expense.
+bool glyph_tile(const pcr_hip_engine* e, const GlyphDev& gl, unsigned mask, GlyphTile* out, int* band_rows) {
+    const GridDev& g = e->gd;
     const int limit = 150 * 1024 / std::max(cell_bytes(gl.type, mask), 4);    // LDS cells per workgroup
     const int side = ((int)std::floor(std::sqrt((double)limit))) & ~1;
     const int need = apron_needed(g, gl);
     int S = std::min(128, (side - 2 * need) & ~7);
     if (S < 32) S = 32;
-    // bins must fit the binning passes' LDS histogram
-    auto nbins_for = [&](int s) { return ((g.W + s - 1) / s) * ((g.st_rows + s - 1) / s); };
-    while (nbins_for(S) > kMaxBins && S < side - 8) S += 8;
-    if (nbins_for(S) > kMaxBins) return false;
+    auto bands_for = [&](int s) {
+        const int br = band_rows_for(g, s, s, e->max_bins);
+        return br > 0 ? (g.st_rows + br - 1) / br : 1 << 30;
+    };
+    while (bands_for(S) > kMaxBands && S < side - 8) S += 8;
+    if (bands_for(S) > kMaxBands) return false;
     GlyphTile t;
     t.need = need;
     t.apron = std::max(0, std::min(need, (side - S) / 2));
@@ -219,6 +225,9 @@ bool glyph_tile(const GridDev& g, const GlyphDev& gl, unsigned mask, GlyphTile* 
     t.bins.tile_w = S;
     t.bins.tile_h = S;
     t.bins.bins_x = (g.W + S - 1) / S;
+    *band_rows = band_rows_for(g, S, S, e->max_bins);
+    t.bins.row0 = 0;
+    t.bins.rows = g.st_rows;
     t.bins.bins_y = (g.st_rows + S - 1) / S;
     t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
     t.bins.chunk = t.bins.nbins <= 2048 ? 16384 : 8192;
@@ -227,10 +236,10 @@ bool glyph_tile(const GridDev& g, const GlyphDev& gl, unsigned mask, GlyphTile* 
 }
 
 template <typename K>
-void launch_tile(K kernel, pcr_hip_engine* e, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
+void launch_tile(K kernel, pcr_hip_engine* e, const GridDev& gd, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
                  const BinBuffers& bb, size_t lds, const double* x, const double* y, const float* v) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, gl, t, pl, bb.records,
+    hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, gl, t, pl, bb.records,
                        bb.items, bb.n_items, x, y, v);
 }
 
@@ -242,7 +251,8 @@ bool binned_glyph_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_
     if (mask == 0 || (mask & ~3u)) return false;
     if (gl.type != PCR_HIP_GLYPH_GAUSSIAN && gl.type != PCR_HIP_GLYPH_LINE) return false;
     GlyphTile t;
-    if (!glyph_tile(e->gd, gl, mask, &t)) return false;
+    int band_rows = 0;
+    if (!glyph_tile(e, gl, mask, &t, &band_rows)) return false;
     // every bin's window is swept once per scatter: not worth it for a handful of points
     uint64_t cells = (uint64_t)e->gd.W * e->gd.st_rows;
     if (e->forced_path != 2 && e->stats.points_in * 64 < cells) return false;
@@ -252,30 +262,49 @@ bool binned_glyph_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_
 int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n) {
     GlyphTile t;
-    if (!glyph_tile(e->gd, gl, mask, &t)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: grid cannot be binned");
+    int band_rows = 0;
+    if (!glyph_tile(e, gl, mask, &t, &band_rows)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: grid cannot be binned");
     // work item size: ~4 M cell updates per workgroup for the Gaussian, 64 K segments for the Line
     unsigned item_points = 65536;
     if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
         double fp = (2.0 * t.need + 1.0) * (2.0 * t.need + 1.0);
         item_points = (unsigned)std::min(65536.0, std::max(1024.0, 4.0e6 / fp));
     }
-    BinBuffers bb{};
-    int rc = bin_points(e, t.bins, x, y, nullptr, n, true, item_points, &bb);
-    if (rc) return rc;
     const size_t lds = (size_t)t.lw * t.lh * cell_bytes(gl.type, mask);
-    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
-        ScopedKernelTimer tm(e, "k_tile_gauss");
-        switch (mask) {
-            case 1: launch_tile(&k_tile_gauss<1>, e, gl, t, pl, bb, lds, x, y, v); break;
-            case 2: launch_tile(&k_tile_gauss<2>, e, gl, t, pl, bb, lds, x, y, v); break;
-            default: launch_tile(&k_tile_gauss<3>, e, gl, t, pl, bb, lds, x, y, v); break;
-        }
-    } else {
-        ScopedKernelTimer tm(e, "k_tile_line");
-        switch (mask) {
-            case 1: launch_tile(&k_tile_line<1>, e, gl, t, pl, bb, lds, x, y, v); break;
-            case 2: launch_tile(&k_tile_line<2>, e, gl, t, pl, bb, lds, x, y, v); break;
-            default: launch_tile(&k_tile_line<3>, e, gl, t, pl, bb, lds, x, y, v); break;
+    const int S = t.bins.tile_h;
+    int total_bins = 0;
+    // row bands: a band bins the points whose CENTRE row it holds; footprints reach into neighbouring
+    // bands through the apron / global-atomic spill exactly as they reach into neighbouring tiles
+    for (int row0 = 0; row0 < e->gd.st_rows; row0 += band_rows) {
+        const int rows = std::min(band_rows, e->gd.st_rows - row0);
+        GridDev gd = e->gd;
+        gd.own_r0 = std::max(e->gd.own_r0, e->gd.st_r0 + row0);
+        gd.own_r1 = std::min(e->gd.own_r1, e->gd.st_r0 + row0 + rows);
+        if (gd.own_r0 >= gd.own_r1) continue;
+        t.bins.row0 = row0;
+        t.bins.rows = rows;
+        t.bins.bins_y = (rows + S - 1) / S;
+        t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
+        t.bins.chunk = t.bins.nbins <= 2048 ? 16384 : 8192;
+        total_bins += t.bins.nbins;
+        BinBuffers bb{};
+        int rc = bin_points(e, gd, t.bins, x, y, nullptr, n, true, item_points, &bb);
+        if (rc) return rc;
+        // the tile kernels re-derive every point's geometry from the engine's grid: the band only selected them
+        if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
+            ScopedKernelTimer tm(e, "k_tile_gauss");
+            switch (mask) {
+                case 1: launch_tile(&k_tile_gauss<1>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                case 2: launch_tile(&k_tile_gauss<2>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                default: launch_tile(&k_tile_gauss<3>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+            }
+        } else {
+            ScopedKernelTimer tm(e, "k_tile_line");
+            switch (mask) {
+                case 1: launch_tile(&k_tile_line<1>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                case 2: launch_tile(&k_tile_line<2>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                default: launch_tile(&k_tile_line<3>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+            }
         }
     }
     PCR_HIP_TRY(hipGetLastError());
@@ -283,7 +312,7 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
     e->stats.lds_tile_w = t.bins.tile_w;
     e->stats.lds_tile_h = t.bins.tile_h;
     e->stats.lds_apron = t.apron;
-    e->stats.num_bins = t.bins.nbins;
+    e->stats.num_bins = total_bins;
     return PCR_HIP_OK;
 }
 

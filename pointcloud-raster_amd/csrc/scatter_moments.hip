@@ -725,6 +725,8 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     p.bins.bins_y = (g.st_rows + kTileH - 1) / kTileH;
     p.bins.nbins = p.bins.bins_x * p.bins.bins_y;
     p.bins.chunk = kScatterPer * kThreads;
+    p.bins.row0 = 0;
+    p.bins.rows = g.st_rows;
     if (p.bins.nbins > 2560) return false;                             // scatter staging: 128 KB + 12 B per bin
     *out = p;
     return true;

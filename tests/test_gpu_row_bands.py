@@ -1,0 +1,111 @@
+"""Row-band sweep of the binned paths: a grid with more LDS tiles than one binning pass takes is
+processed band by band (scatter_binned.hip / scatter_binned_glyph.hip).  PCR_HIP_DEBUG_MAX_BINS lowers
+the per-pass limit (8064) so that the sweep is reached on grids the oracle finishes in seconds; the
+same bars as everywhere else apply (Count/Min/Max bit-exact, sums 1e-5, glyphs rtol 1e-4)."""
+import numpy as np
+import pytest
+
+import pcr_oracle_py as O
+from conftest import assert_band_close, load_cabi
+
+pytestmark = pytest.mark.gpu
+RT = {"Sum": 0, "Max": 1, "Min": 2, "Average": 3, "WeightedAverage": 4, "Count": 5}
+
+
+@pytest.fixture(scope="module")
+def A():
+    return load_cabi()
+
+
+@pytest.fixture()
+def few_bins(monkeypatch):
+    monkeypatch.setenv("PCR_HIP_DEBUG_MAX_BINS", "6")      # read by pcr_hip_engine_create
+    yield 6
+
+
+def mask_for(A, rtype):
+    return {0: A.PLANE_SUM, 1: A.PLANE_MAX, 2: A.PLANE_MIN, 3: 3, 4: 3, 5: A.PLANE_WGT}[rtype]
+
+
+def run_gpu(A, og, rtype, x, y, v, glyph=None, own_rows=None, halo=0, **ch):
+    grid = A.make_grid((og.min_x, og.min_y, og.max_x, og.max_y), cell=(og.cell_size_x, og.cell_size_y),
+                       dims=(og.width, og.height), tile=(og.tile_width, og.tile_height), own_rows=own_rows, halo=halo)
+    run = A.ReductionRun(grid, mask_for(A, rtype), path=2)
+    try:
+        run.scatter(x, y, v, glyph=glyph, **ch)
+        return run.finalize(rtype), run.stats()
+    finally:
+        run.close()
+
+
+@pytest.mark.parametrize("rname", ["Sum", "Count", "Average", "Max", "Min"])
+def test_point_bands_match_oracle(A, few_bins, rname):
+    # 300 x 700 cells = 3 x 8 tiles of 128 x 96 (Sum+Count) -> at most 2 tile rows per band
+    og = O.make_grid((0.0, 0.0, 300.0, 700.0), tile=(64, 64))
+    rng = np.random.default_rng(11)
+    n = 200_000
+    x = rng.uniform(-3.0, 303.0, n)
+    y = rng.uniform(-3.0, 703.0, n)
+    v = rng.normal(0.0, 5.0, n).astype(np.float32)
+    rt = RT[rname]
+    got, st = run_gpu(A, og, rt, x, y, v)
+    assert st.path == 1 and st.num_bins > few_bins, "the band sweep was not taken"
+    want = O.run(og, rt, x, y, v)
+    exact = O.run(og, rt, x, y, v, wide=True)
+    ref = O.Reduction(og, rt)
+    ref.ingest(x, y, v)
+    assert st.points_valid == ref.points_valid()
+    if rname in ("Count", "Max", "Min"):
+        assert_band_close(got, want, what=f"{rname} bit-exact")
+    else:
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        fin = ~np.isnan(exact)
+        err = np.abs(got[fin].astype(np.float64) - exact[fin])
+        tol = 1e-5 * np.maximum(1.0, np.abs(exact[fin])) * (5.0 if rname == "Sum" else 1.0)   # N(0,5) values
+        assert (err <= tol).all(), f"max err {err.max()}"
+
+
+@pytest.mark.parametrize("kind", ["gauss", "line"])
+def test_glyph_bands_match_oracle(A, few_bins, kind):
+    og = O.make_grid((0.0, 0.0, 200.0, 600.0), tile=(4096, 4096))
+    rng = np.random.default_rng(12)
+    n = 20_000
+    x = rng.uniform(-2.0, 202.0, n)
+    y = rng.uniform(-2.0, 602.0, n)
+    v = rng.uniform(1.0, 2.0, n).astype(np.float32)
+    if kind == "gauss":
+        gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=1.5, max_radius=6.0)
+        ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=1.5, max_radius=6.0)
+        ch = {}
+    else:
+        gl = dict(type=A.GLYPH_LINE, half_length=9.0, max_radius=32.0)
+        ogl = O.make_glyph(O.GLYPH_LINE, half_length=9.0, max_radius=32.0)
+        ch = dict(direction=rng.uniform(0.0, 2 * np.pi, n).astype(np.float32))
+    rt = RT["WeightedAverage"]
+    got, st = run_gpu(A, og, rt, x, y, v, glyph=gl, **ch)
+    assert st.path == 1 and st.num_bins > few_bins
+    want = O.run(og, rt, x, y, v, glyph=ogl, **ch)
+    exact = O.run(og, rt, x, y, v, glyph=ogl, wide=True, **ch).astype(np.float64)
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert (gn != wn).sum() <= (0 if kind == "line" else 2)
+    both = ~gn & ~wn
+    err = np.abs(got[both].astype(np.float64) - exact[both])
+    assert (err <= 1e-4 * np.maximum(1e-3, np.abs(exact[both]))).all()
+    # Count through the same path is exact for the Line (integer weights)
+    if kind == "line":
+        gotc, _ = run_gpu(A, og, RT["Count"], x, y, v, glyph=gl, **ch)
+        np.testing.assert_array_equal(gotc, O.run(og, RT["Count"], x, y, v, glyph=ogl, **ch))
+
+
+def test_point_bands_inside_a_row_block_shard(A, few_bins):
+    """Bands and the owned-row window compose: a shard owning rows [200, 520) of 700."""
+    og = O.make_grid((0.0, 0.0, 300.0, 700.0))
+    rng = np.random.default_rng(13)
+    n = 100_000
+    x, y = rng.uniform(0, 300, n), rng.uniform(0, 700, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    got, st = run_gpu(A, og, RT["Count"], x, y, v, own_rows=(200, 520))
+    want = O.run(og, RT["Count"], x, y, v)[200:520]
+    # untouched-tile NaN semantics are per reference tile (one 4096^2 tile here): compare counts where defined
+    np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want))
+    assert st.points_valid == int(np.nansum(want))
