@@ -67,8 +67,14 @@ constexpr int kMaxBands = 32;           // a grid with more LDS tiles than kMaxB
 struct BinItem {                        // one workgroup's share of a bin's records
     unsigned bin, first, count, shared; // shared != 0: the bin was split, merge with atomics
 };
+struct GlyphRec {                       // glyph paths: everything a footprint needs, so that tiles never gather by index
+    double x, y;
+    float v, c0, c1, c2;                // value; per-point channels (GlyphChan)
+};
+static_assert(sizeof(GlyphRec) == 32, "glyph records are two 16-byte halves");
 struct BinBuffers {                     // device pointers into the engine's scratch arena
-    const uint2* records;               // grouped by bin; .x = local cell, .y = value bits or point index
+    const uint2* records;               // Value / Index records, grouped by bin; .x = local cell
+    const GlyphRec* grecords;           // glyphs: grouped by bin
     const BinItem* items;
     const unsigned* n_items;
     int max_items;
@@ -86,12 +92,13 @@ inline int band_rows_for(const GridDev& g, int tile_w, int tile_h, int max_bins)
 }
 
 // Passes A (histogram + routing keys), scan, B (LDS-staged scatter) over the points that gd owns (for a band:
-// the engine's grid with the owned rows narrowed to the band).  index_records: record.y is
-// the point's index (glyph paths re-read x, y, v, channels by index) instead of its value.
-// extra_scratch bytes are reserved after the binning buffers and returned through *extra.
+// the engine's grid with the owned rows narrowed to the band).  Record kinds:
+//   Value  8 B {local cell, value}         Point glyph
+//   Index  8 B {local cell, point index}   Gaussian tiles (LDS-atomic bound: gathering x, y, v by index hides behind it)
+//   Glyph  32 B GlyphRec                   Line tiles (the gather was their whole run time), needs gl
+enum class RecordKind { Value, Index, Glyph };
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
-               uint64_t n, bool index_records, unsigned item_records, BinBuffers* out,
-               size_t extra_scratch = 0, void** extra = nullptr);
+               uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out);
 
 // direct path (global atomics), scatter_direct.hip
 int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,

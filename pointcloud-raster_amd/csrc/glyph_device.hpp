@@ -45,6 +45,25 @@ __device__ __forceinline__ void sincos_like_libm(float a, float& s, float& c) {
     c = (float)cd;
 }
 
+// Per-point channel values of a glyph (only the ones whose GlyphDev pointer is set are meaningful):
+// Gaussian: c0 = sigma_x, c1 = sigma_y, c2 = rotation; Line: c0 = direction, c1 = half_length.
+struct GlyphChan {
+    float c0, c1, c2;
+};
+
+__device__ __forceinline__ GlyphChan load_chan(const GlyphDev& gl, uint64_t i) {
+    GlyphChan c{0.f, 0.f, 0.f};
+    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
+        if (gl.sigma_x) c.c0 = gl.sigma_x[i];
+        if (gl.sigma_y) c.c1 = gl.sigma_y[i];
+        if (gl.rotation) c.c2 = gl.rotation[i];
+    } else {
+        if (gl.direction) c.c0 = gl.direction[i];
+        if (gl.half_length) c.c1 = gl.half_length[i];
+    }
+    return c;
+}
+
 // ---- Gaussian ------------------------------------------------------------------
 struct GaussParams {
     float val, sub_cx, sub_cy, sx, sy, cos_r, sin_r;
@@ -54,18 +73,18 @@ struct GaussParams {
 
 // glyph_kernels.cu:105-145 for the lane's own point.
 __device__ __forceinline__ GaussParams gauss_params(const GridDev& g, const GlyphDev& gl,
-                                                    const PointGeom& pg, float val, uint64_t i) {
+                                                    const PointGeom& pg, float val, const GlyphChan& ch) {
     GaussParams q;
     q.val = val;
     double flx = floor(pg.fcx), fly = floor(pg.fcy);
     q.sub_cx = (float)(pg.fcx - flx);
     q.sub_cy = (float)(pg.fcy - fly);
     float sxw = gl.def_sigma_x, syw = gl.def_sigma_y;
-    if (gl.sigma_x) { float t = gl.sigma_x[i]; if (t > 0.0f) sxw = t; }
-    if (gl.sigma_y) { float t = gl.sigma_y[i]; if (t > 0.0f) syw = t; }
+    if (gl.sigma_x) { float t = ch.c0; if (t > 0.0f) sxw = t; }
+    if (gl.sigma_y) { float t = ch.c1; if (t > 0.0f) syw = t; }
     q.sx = sxw * (float)g.inv_csx;
     q.sy = syw * (float)g.inv_csy;
-    float rot = gl.rotation ? gl.rotation[i] : gl.def_rotation;
+    float rot = gl.rotation ? ch.c2 : gl.def_rotation;
     sincos_like_libm(-rot, q.sin_r, q.cos_r);
     float R = fminf(3.0f * fmaxf(q.sx, q.sy), gl.max_radius);
     // a NaN/huge radius cannot run away: the clip rectangle bounds the loop below
@@ -214,11 +233,11 @@ struct LineParams {
 
 // glyph_kernels.cu:213-250.
 __device__ __forceinline__ LineParams line_params(const GridDev& g, const GlyphDev& gl,
-                                                  const PointGeom& pg, float val, uint64_t i) {
+                                                  const PointGeom& pg, float val, const GlyphChan& ch) {
     LineParams q;
     q.val = val;
-    float direction = gl.direction ? gl.direction[i] : gl.def_direction;
-    float half_len = gl.half_length ? gl.half_length[i] : gl.def_half_length;
+    float direction = gl.direction ? ch.c0 : gl.def_direction;
+    float half_len = gl.half_length ? ch.c1 : gl.def_half_length;
     float hx = half_len * (float)g.inv_csx;
     float hy = half_len * (float)g.inv_csy;
     hx = fminf(hx, gl.max_radius);                 // std::min(h, cap): hy < 0 is never capped (Q7)

@@ -158,7 +158,7 @@ k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_co
 // ---- pass B: scatter records, staged through LDS so that every bin's run is written contiguously
 // VEC: every block of the launch is a full chunk and keys/v are 16-byte aligned (16-byte loads,
 // four consecutive points per lane); the ragged last chunk is a second, scalar launch.
-// INDEX: record.y = index of the point instead of its value.
+// INDEX: record.y = index of the point instead of its value (Gaussian tiles: LDS-atomic bound, the gather is free).
 template <int PER_THREAD, bool VEC, bool INDEX>
 __global__ void __launch_bounds__(kThreads)
 k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, const float* __restrict__ v,
@@ -255,6 +255,71 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
         unsigned bin = rec.x >> kLcellBits;
         unsigned dst = gbase[bin] + (j - loff[bin]);
         records[dst] = make_uint2(rec.x & kLcellMask, rec.y);
+    }
+}
+
+// ---- pass B for glyphs: 32-byte records {x, y, value, channels}, written straight from registers ----
+// A glyph tile needs the point's exact f64 position and its channels; fetching them by index from the
+// tile kernel costs a 64-byte sector per 4-8 useful bytes (13 GB per 50 M points, measured as the whole
+// run time of k_tile_line).  Here they are read once, coalesced, and travel with the record.  No LDS
+// staging of the data: a lane stores its own record (two 16-byte stores); the records of one (block, bin)
+// run are adjacent in memory and meet in L2.
+constexpr int kRecKeys = 16;                    // keys per thread: 16384-point chunks whatever the bin count,
+constexpr int kRecChunk = kRecKeys * kThreads;  // so that a (block, bin) run is a few records long
+constexpr int kRecBatch = 8;                    // records assembled per thread at a time
+
+__global__ void __launch_bounds__(kThreads)
+k_rec_scatter(BinGeom b, GlyphDev gl, const unsigned* __restrict__ keys, const double* __restrict__ x,
+              const double* __restrict__ y, const float* __restrict__ v, uint64_t n,
+              unsigned* __restrict__ cursor, GlyphRec* __restrict__ records) {
+    extern __shared__ unsigned lds_u32[];
+    unsigned* hist = lds_u32;                   // [nbins]  then reused as the bin's global base
+    for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kRecChunk;
+    const float* ch0 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.sigma_x : gl.direction;
+    const float* ch1 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.sigma_y : gl.half_length;
+    const float* ch2 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.rotation : nullptr;
+    unsigned key[kRecKeys], rank[kRecKeys];
+#pragma unroll
+    for (int k = 0; k < kRecKeys; ++k) {
+        const uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+        key[k] = i < n ? keys[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < kRecKeys; ++k) {
+        rank[k] = 0;
+        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < b.nbins; i += kThreads) {
+        const unsigned c = hist[i];
+        if (c) hist[i] = atomicAdd(&cursor[i], c);          // now: where this block's run of bin i starts
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < kRecKeys; k0 += kRecBatch) {
+        double wx[kRecBatch], wy[kRecBatch];
+        float val[kRecBatch], c0[kRecBatch], c1[kRecBatch], c2[kRecBatch];
+#pragma unroll
+        for (int u = 0; u < kRecBatch; ++u) {   // the batch's loads in flight before the first store
+            const uint64_t i = base + (uint64_t)(k0 + u) * kThreads + threadIdx.x;
+            const uint64_t ic = i < n ? i : n - 1;
+            wx[u] = x[ic];
+            wy[u] = y[ic];
+            val[u] = v ? v[ic] : 0.f;
+            c0[u] = ch0 ? ch0[ic] : 0.f;
+            c1[u] = ch1 ? ch1[ic] : 0.f;
+            c2[u] = ch2 ? ch2[ic] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kRecBatch; ++u) {
+            const unsigned kk = key[k0 + u];
+            if (kk == 0xFFFFFFFFu) continue;
+            GlyphRec r;
+            r.x = wx[u]; r.y = wy[u]; r.v = val[u]; r.c0 = c0[u]; r.c1 = c1[u]; r.c2 = c2[u];
+            records[hist[kk >> kLcellBits] + rank[k0 + u]] = r;
+        }
     }
 }
 
@@ -406,19 +471,18 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 namespace pcrhip {
 
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
-               uint64_t n, bool index_records, unsigned item_records, BinBuffers* out,
-               size_t extra_scratch, void** extra) {
+               uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out) {
     const int blocks = (int)((n + b.chunk - 1) / b.chunk);
     const int max_items = b.nbins + (int)(n / item_records) + 1;
+    const size_t rec_bytes = kind == RecordKind::Glyph ? sizeof(GlyphRec) : sizeof(uint2);
 
     size_t off = 0;                                             // scratch carve-up
     const size_t o_count = off;  off += align256((size_t)b.nbins * 4);
     const size_t o_cursor = off; off += align256((size_t)b.nbins * 4);
     const size_t o_nitems = off; off += 256;
     const size_t o_items = off;  off += align256((size_t)max_items * sizeof(BinItem));
-    const size_t o_rec = off;    off += align256((size_t)n * sizeof(uint2));
+    const size_t o_rec = off;    off += align256((size_t)n * rec_bytes);
     const size_t o_keys = off;   off += align256((size_t)n * sizeof(unsigned));
-    const size_t o_extra = off;  off += align256(extra_scratch);
     int rc = ensure_scratch(e, off);
     if (rc) return rc;
     char* s = e->d_scratch;
@@ -426,9 +490,7 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     unsigned* d_cursor = reinterpret_cast<unsigned*>(s + o_cursor);
     unsigned* d_nitems = reinterpret_cast<unsigned*>(s + o_nitems);
     BinItem* d_items = reinterpret_cast<BinItem*>(s + o_items);
-    uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
     unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
-    if (extra) *extra = s + o_extra;
 
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     {
@@ -441,9 +503,22 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, item_records, d_count,
                            d_cursor, d_items, d_nitems);
     }
-    {
+    if (kind == RecordKind::Glyph) {
+        ScopedKernelTimer t(e, "k_rec_scatter");
+        GlyphRec* d_rec = reinterpret_cast<GlyphRec*>(s + o_rec);
+        const size_t lds = (size_t)b.nbins * 4;
+        const int rblocks = (int)((n + kRecChunk - 1) / kRecChunk);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rec_scatter),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_rec_scatter, dim3(rblocks), dim3(kThreads), lds, e->stream, b, *gl, d_keys, x, y, v, n,
+                           d_cursor, d_rec);
+        out->records = nullptr;
+        out->grecords = d_rec;
+    } else {
         ScopedKernelTimer t(e, "k_bin_scatter");
+        uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
         const size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 3;
+        const bool index_records = kind == RecordKind::Index;
         const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;   // d_keys is 256-B aligned
         const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
         auto launch = [&](auto kernel, int nblocks, int first) {
@@ -466,9 +541,10 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
             launch(&k_bin_scatter<8, true, true>, full_blocks, 0);
             launch(&k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
         }
+        out->records = d_rec;
+        out->grecords = nullptr;
     }
     PCR_HIP_TRY(hipGetLastError());
-    out->records = d_rec;
     out->items = d_items;
     out->n_items = d_nitems;
     out->max_items = max_items;
@@ -512,7 +588,7 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
         b = point_bin_geom(e->gd, mask, row0, rows);
         total_bins += b.nbins;
         BinBuffers bb{};
-        int rc = bin_points(e, gd, b, x, y, v, n, false, kPointItemRecords, &bb);
+        int rc = bin_points(e, gd, b, x, y, v, n, RecordKind::Value, nullptr, kPointItemRecords, &bb);
         if (rc) return rc;
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {

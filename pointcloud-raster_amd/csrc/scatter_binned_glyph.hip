@@ -1,6 +1,7 @@
 // scatter_binned_glyph.hip -- Gaussian / Line glyphs on LDS tiles.
 //
-// Points are binned by the LDS tile that contains their CENTRE cell (bin_points, index records).
+// Points are binned by the LDS tile that contains their CENTRE cell (bin_points): index records for the
+// Gaussian, 32-byte position + value + channel records for the Line (see RecordKind, engine.hpp).
 // One workgroup per work item keeps an LDS window = the bin's interior plus an apron of A cells
 // on every side, paints its points' footprints into it with LDS atomics (ds_add_f64 for the
 // v*w and w sums of the Gaussian, ds_add_f64 + ds_add_u32 for the Line -- ds_add_f32 is ~28x
@@ -101,10 +102,11 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
         bool valid = j < it.count;
         GaussParams q{};
         if (valid) {
-            uint64_t i = rec[j].y;
+            // index records: this kernel is bound by LDS-atomic issue, the gather of x, y, v hides behind it
+            const uint64_t i = rec[j].y;
             PointGeom pg = point_geom(g, x[i], y[i]);
             valid = pg.valid;                     // always true for a binned point; keeps q sane
-            if (valid) q = gauss_params(g, gl, pg, v[i], i);
+            if (valid) q = gauss_params(g, gl, pg, v[i], load_chan(gl, i));
         }
         // small footprints (<= 11 x 11): one lane per point; larger ones: the whole wave per point
         const bool big = valid && q.r > 5;
@@ -138,9 +140,8 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
 // ---- Line tiles ---------------------------------------------------------------------------------------
 template <unsigned MASK>
 __global__ void __launch_bounds__(kThreads)
-k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __restrict__ records,
-            const BinItem* __restrict__ items, const unsigned* __restrict__ n_items,
-            const double* __restrict__ x, const double* __restrict__ y, const float* __restrict__ v) {
+k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const GlyphRec* __restrict__ records,
+            const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
     extern __shared__ double lds_win[];
     if (blockIdx.x >= *n_items) return;
     const BinItem it = items[blockIdx.x];
@@ -156,12 +157,12 @@ k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __re
     const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
     LineLdsSink<MASK> sink{g, pl, t_s, t_c, bx * t.bins.tile_w - t.apron,
                            g.st_r0 + t.bins.row0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
-    const uint2* rec = records + it.first;
+    const GlyphRec* rec = records + it.first;
     for (unsigned j = threadIdx.x; j < it.count; j += kThreads) {
-        uint64_t i = rec[j].y;
-        PointGeom pg = point_geom(g, x[i], y[i]);
+        const GlyphRec rc = rec[j];
+        PointGeom pg = point_geom(g, rc.x, rc.y);
         if (!pg.valid) continue;
-        LineParams q = line_params(g, gl, pg, v[i], i);
+        LineParams q = line_params(g, gl, pg, rc.v, GlyphChan{rc.c0, rc.c1, rc.c2});
         line_walk(q, sink);
     }
     __syncthreads();
@@ -236,11 +237,19 @@ bool glyph_tile(const pcr_hip_engine* e, const GlyphDev& gl, unsigned mask, Glyp
 }
 
 template <typename K>
-void launch_tile(K kernel, pcr_hip_engine* e, const GridDev& gd, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
-                 const BinBuffers& bb, size_t lds, const double* x, const double* y, const float* v) {
+void launch_gauss(K kernel, pcr_hip_engine* e, const GridDev& gd, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
+                  const BinBuffers& bb, size_t lds, const double* x, const double* y, const float* v) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, gl, t, pl, bb.records,
                        bb.items, bb.n_items, x, y, v);
+}
+
+template <typename K>
+void launch_line(K kernel, pcr_hip_engine* e, const GridDev& gd, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
+                 const BinBuffers& bb, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, gl, t, pl, bb.grecords,
+                       bb.items, bb.n_items);
 }
 
 }  // namespace
@@ -288,22 +297,23 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
         t.bins.chunk = t.bins.nbins <= 2048 ? 16384 : 8192;
         total_bins += t.bins.nbins;
         BinBuffers bb{};
-        int rc = bin_points(e, gd, t.bins, x, y, nullptr, n, true, item_points, &bb);
+        const bool is_line = gl.type == PCR_HIP_GLYPH_LINE;
+        int rc = bin_points(e, gd, t.bins, x, y, v, n, is_line ? RecordKind::Glyph : RecordKind::Index, &gl, item_points, &bb);
         if (rc) return rc;
         // the tile kernels re-derive every point's geometry from the engine's grid: the band only selected them
         if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
             ScopedKernelTimer tm(e, "k_tile_gauss");
             switch (mask) {
-                case 1: launch_tile(&k_tile_gauss<1>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
-                case 2: launch_tile(&k_tile_gauss<2>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
-                default: launch_tile(&k_tile_gauss<3>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                case 1: launch_gauss(&k_tile_gauss<1>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                case 2: launch_gauss(&k_tile_gauss<2>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                default: launch_gauss(&k_tile_gauss<3>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
             }
         } else {
             ScopedKernelTimer tm(e, "k_tile_line");
             switch (mask) {
-                case 1: launch_tile(&k_tile_line<1>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
-                case 2: launch_tile(&k_tile_line<2>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
-                default: launch_tile(&k_tile_line<3>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+                case 1: launch_line(&k_tile_line<1>, e, e->gd, gl, t, pl, bb, lds); break;
+                case 2: launch_line(&k_tile_line<2>, e, e->gd, gl, t, pl, bb, lds); break;
+                default: launch_line(&k_tile_line<3>, e, e->gd, gl, t, pl, bb, lds); break;
             }
         }
     }

@@ -87,7 +87,7 @@ k_gauss_direct(GridDev g, GlyphDev gl, PlanesDev pl, const double* __restrict__ 
             PointGeom pg = point_geom(g, x[i], y[i]);
             valid = pg.valid && point_kept(g, i);
             if (valid) {
-                q = gauss_params(g, gl, pg, v[i], i);
+                q = gauss_params(g, gl, pg, v[i], load_chan(gl, i));
                 touch_tile(g, touched, pg.row, pg.col);
             }
         }
@@ -123,7 +123,7 @@ k_line_direct(GridDev g, GlyphDev gl, PlanesDev pl, const double* __restrict__ x
             PointGeom pg = point_geom(g, x[i], y[i]);
             valid = pg.valid && point_kept(g, i);
             if (valid) {
-                LineParams q = line_params(g, gl, pg, v[i], i);
+                LineParams q = line_params(g, gl, pg, v[i], load_chan(gl, i));
                 touch_tile(g, touched, pg.row, pg.col);
                 line_walk(q, sink);
             }

@@ -676,7 +676,7 @@ k_gauss_list(GridDev g, GlyphDev gl, PlanesDev pl, const unsigned* __restrict__ 
             uint64_t i = list[j];
             PointGeom pg = point_geom(g, x[i], y[i]);
             valid = pg.valid;
-            if (valid) q = gauss_params(g, gl, pg, v[i], i);
+            if (valid) q = gauss_params(g, gl, pg, v[i], load_chan(gl, i));
         }
         unsigned long long todo = __ballot(valid);
         while (todo) {
