@@ -14,6 +14,7 @@
 #include "buffer.h"
 #include "pcr/core/grid.h"
 #include "pcr/core/point_cloud.h"
+#include "pcr/io/grid_io.h"
 #include "pcr/io/tile_state_io.h"
 
 #include <algorithm>
@@ -446,10 +447,23 @@ struct Pipeline::Impl {
         s = detail::hip_status(pcr_hip_stream_synchronize(stream));
         if (!s.ok()) return s;
         finalized = true;
-        if (!cfg.output_path.empty())
-            return Status::error(StatusCode::NotImplemented,
-                "pipeline: output_path is set but GeoTIFF writing is not part of this build "
-                "(the finalized grid is available through result())");
+        if (!cfg.output_path.empty()) {
+            // pipeline.cpp:1351-1361 of the reference: the finalized grid goes to output_path as GeoTIFF.
+            // A shard writes its own row block (georeferenced as such); a device-resident result is copied out first.
+            GridConfig out_cfg = cfg.grid;
+            if (rows != cfg.grid.height) {
+                out_cfg.height = rows;
+                out_cfg.bounds.max_y = cfg.grid.bounds.max_y + hg.own_row0 * cfg.grid.cell_size_y;
+                out_cfg.bounds.min_y = out_cfg.bounds.max_y + rows * cfg.grid.cell_size_y;
+                if (out_cfg.bounds.min_y > out_cfg.bounds.max_y) std::swap(out_cfg.bounds.min_y, out_cfg.bounds.max_y);
+            }
+            if (on_device) {
+                std::unique_ptr<Grid> host = result->to(MemoryLocation::Host);
+                if (!host) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to copy the result grid to the host");
+                return write_geotiff(cfg.output_path, *host, out_cfg, GeoTiffOptions());
+            }
+            return write_geotiff(cfg.output_path, *result, out_cfg, GeoTiffOptions());
+        }
         return Status::success();
     }
 

@@ -244,6 +244,23 @@ void bind_core(py::module_& m) {
             require_host(pc.location(), "set_channel_array_f32");
             copy_in<float>(p, a, pc.count(), "Array size exceeds point count");
         })
+        // extension: any channel as a zero-copy array of its own dtype (files carry f64 / i32 / u32 channels too)
+        .def("channel_array", [](PointCloud& pc, const std::string& name) -> py::object {
+            const ChannelDesc* d = pc.channel(name);
+            void* p = pc.channel_data(name);
+            if (!d || !p) throw std::runtime_error("Channel not found: " + name);
+            require_host(pc.location(), "channel_array");
+            py::object owner = py::cast(&pc);
+            switch (d->dtype) {
+                case DataType::Float32: return host_view<float>(static_cast<float*>(p), pc.count(), owner, "channel_array");
+                case DataType::Float64: return host_view<double>(static_cast<double*>(p), pc.count(), owner, "channel_array");
+                case DataType::Int32: return host_view<int32_t>(static_cast<int32_t*>(p), pc.count(), owner, "channel_array");
+                case DataType::UInt32: return host_view<uint32_t>(static_cast<uint32_t*>(p), pc.count(), owner, "channel_array");
+                case DataType::Int16: return host_view<int16_t>(static_cast<int16_t*>(p), pc.count(), owner, "channel_array");
+                case DataType::UInt16: return host_view<uint16_t>(static_cast<uint16_t*>(p), pc.count(), owner, "channel_array");
+                default: return host_view<uint8_t>(static_cast<uint8_t*>(p), pc.count(), owner, "channel_array");
+            }
+        })
         .def("to_device", [](const PointCloud& pc) {
             auto d = pc.to(MemoryLocation::Device);
             if (!d) throw std::runtime_error("Failed to transfer point cloud to Device memory "

@@ -1,46 +1,18 @@
-// bind_io.cpp -- names of the reference's I/O layer (GeoTIFF via GDAL, PCRP/CSV/LAS readers),
-// kept so that `import pcr` exposes the same symbols.  I/O is outside the accelerated
-// ingest->finalize path of this build: every call raises RuntimeError.
+// bind_io.cpp -- the reference's I/O layer at the same Python names (python/bindings.cpp:500-640):
+// PCRP / CSV point clouds, GeoTIFF output of finalized grids, `.pcrt` tile-state checkpoints.
+// LAS/LAZ raise NotImplemented as upstream.
 #include "common.h"
 
 #include "pcr/core/grid.h"
 #include "pcr/core/grid_config.h"
 #include "pcr/core/point_cloud.h"
+#include "pcr/io/grid_io.h"
+#include "pcr/io/point_cloud_io.h"
 #include "pcr/io/tile_state_io.h"
 
 #include <vector>
 
 using namespace pcr;
-
-namespace {
-
-enum class PointCloudFormat : uint8_t { PCR_Binary, CSV, LAS, LAZ, Auto };
-
-struct GeoTiffOptions {
-    bool cloud_optimized = false;
-    std::string compress = "LZW";
-    int compress_level = 6;
-    int tile_width = 256;
-    int tile_height = 256;
-    bool bigtiff = true;
-    std::string overview_resampling = "average";
-};
-
-struct PointCloudInfo {
-    size_t num_points = 0;
-    std::vector<ChannelDesc> channels;
-    CRS crs;
-    BBox bounds;
-};
-
-struct PointCloudReader {};
-
-[[noreturn]] void unavailable(const char* what) {
-    throw std::runtime_error(std::string(what) + ": file I/O is not part of this build "
-                             "(only Pipeline.ingest/finalize is accelerated; use numpy/rasterio for files)");
-}
-
-}  // namespace
 
 void bind_io(py::module_& m) {
     // `.pcrt` tile-state files (the reference's checkpoint format) -- implemented, unlike the rest of I/O
@@ -94,18 +66,71 @@ void bind_io(py::module_& m) {
         .def_readwrite("bounds", &PointCloudInfo::bounds);
 
     py::class_<PointCloudReader>(m, "PointCloudReader")
-        .def_static("open", [](const std::string&, PointCloudFormat) -> PointCloudReader { unavailable("PointCloudReader.open"); },
-                    py::arg("path"), py::arg("format") = PointCloudFormat::Auto);
+        .def_static("open", [](const std::string& path, PointCloudFormat format) {
+            auto r = PointCloudReader::open(path, format);
+            if (!r) throw std::runtime_error("PointCloudReader.open: failed to open " + path);
+            return r;
+        }, py::arg("path"), py::arg("format") = PointCloudFormat::Auto)
+        .def("info", &PointCloudReader::info, py::return_value_policy::reference_internal)
+        .def("read_chunk", &PointCloudReader::read_chunk, py::arg("cloud"), py::arg("max_points"))
+        .def("rewind", [](PointCloudReader& r) { raise_if_error(r.rewind()); })
+        .def("eof", &PointCloudReader::eof);
 
-    m.def("write_geotiff", [](const std::string&, const Grid&, const GridConfig&, const GeoTiffOptions&) {
-        unavailable("write_geotiff");
+    // extension (the reference does not bind it): incremental assembly from reference tiles
+    py::class_<TiledGeoTiffWriter>(m, "TiledGeoTiffWriter")
+        .def_static("open", [](const std::string& path, const GridConfig& config, const std::vector<std::string>& band_names,
+                               const GeoTiffOptions& options) {
+            auto w = TiledGeoTiffWriter::open(path, config, band_names, options);
+            if (!w) throw std::runtime_error("TiledGeoTiffWriter.open: failed to create " + path);
+            return w;
+        }, py::arg("path"), py::arg("config"), py::arg("band_names"), py::arg("options") = GeoTiffOptions())
+        .def("write_tile", [](TiledGeoTiffWriter& w, int tile_row, int tile_col,
+                              py::array_t<float, py::array::c_style | py::array::forcecast> data) {
+            auto b = data.request();
+            if (b.ndim != 3) throw std::runtime_error("write_tile: data must be [bands, rows, cols]");
+            TileIndex t;
+            t.row = tile_row;
+            t.col = tile_col;
+            raise_if_error(w.write_tile(t, static_cast<const float*>(b.ptr), (int)b.shape[0]));
+        }, py::arg("tile_row"), py::arg("tile_col"), py::arg("data"))
+        .def("close", [](TiledGeoTiffWriter& w) { raise_if_error(w.close()); });
+
+    m.def("write_geotiff", [](const std::string& path, const Grid& grid, const GridConfig& config, const GeoTiffOptions& options) {
+        raise_if_error(write_geotiff(path, grid, config, options));
     }, py::arg("path"), py::arg("grid"), py::arg("config"), py::arg("options") = GeoTiffOptions());
-    m.def("read_geotiff_info", [](const std::string&) { unavailable("read_geotiff_info"); });
-    m.def("read_point_cloud", [](const std::string&, PointCloudFormat) { unavailable("read_point_cloud"); },
-          py::arg("path"), py::arg("format") = PointCloudFormat::Auto);
-    m.def("write_point_cloud", [](const std::string&, const PointCloud&, PointCloudFormat) {
-        unavailable("write_point_cloud");
+    m.def("read_geotiff_info", [](const std::string& path) {
+        int w = 0, h = 0, nb = 0;
+        CRS crs;
+        BBox bounds;
+        raise_if_error(read_geotiff_info(path, w, h, nb, crs, bounds));
+        return py::make_tuple(w, h, nb, crs, bounds);
+    }, py::arg("path"));
+    m.def("read_geotiff_band", [](const std::string& path, int band_index) {
+        int w = 0, h = 0, nb = 0;
+        CRS crs;
+        BBox bounds;
+        raise_if_error(read_geotiff_info(path, w, h, nb, crs, bounds));
+        py::array_t<float> out({h, w});
+        raise_if_error(read_geotiff_band(path, band_index, out.mutable_data(), w, h));
+        return out;
+    }, py::arg("path"), py::arg("band_index") = 0);
+    m.def("read_geotiff_band_names", [](const std::string& path) {
+        std::vector<std::string> names;
+        raise_if_error(read_geotiff_band_names(path, names));
+        return names;
+    }, py::arg("path"));
+
+    m.def("read_point_cloud", [](const std::string& path, PointCloudFormat format, MemoryLocation location) {
+        auto c = read_point_cloud(path, format, location);
+        if (!c) throw std::runtime_error("read_point_cloud: failed to read " + path);
+        return c;
+    }, py::arg("path"), py::arg("format") = PointCloudFormat::Auto, py::arg("location") = MemoryLocation::Host);
+    m.def("write_point_cloud", [](const std::string& path, const PointCloud& cloud, PointCloudFormat format) {
+        raise_if_error(write_point_cloud(path, cloud, format));
     }, py::arg("path"), py::arg("cloud"), py::arg("format") = PointCloudFormat::PCR_Binary);
-    m.def("read_point_cloud_info", [](const std::string&, PointCloudFormat) { unavailable("read_point_cloud_info"); },
-          py::arg("path"), py::arg("format") = PointCloudFormat::Auto);
+    m.def("read_point_cloud_info", [](const std::string& path, PointCloudFormat format) {
+        PointCloudInfo info;
+        raise_if_error(read_point_cloud_info(path, info, format));
+        return info;
+    }, py::arg("path"), py::arg("format") = PointCloudFormat::Auto);
 }

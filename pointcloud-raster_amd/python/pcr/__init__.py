@@ -22,6 +22,7 @@ from ._pcr import (  # noqa: E402,F401
     device_count, device_name, pipeline_create_error,
     read_geotiff_info, read_point_cloud, read_point_cloud_info, write_geotiff, write_point_cloud,
     read_tile_state, tile_state_filename, write_tile_state,
+    read_geotiff_band, read_geotiff_band_names, TiledGeoTiffWriter,
 )
 
 
@@ -91,4 +92,5 @@ __all__ = [
     "PointCloudInfo", "read_point_cloud", "write_point_cloud", "read_point_cloud_info", "PointCloudReader",
     "DeviceArrayView", "device_count", "device_name", "pipeline_create_error",
     "read_tile_state", "write_tile_state", "tile_state_filename",
+    "read_geotiff_band", "read_geotiff_band_names", "TiledGeoTiffWriter",
 ]

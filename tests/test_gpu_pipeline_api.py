@@ -132,11 +132,11 @@ def test_error_messages_match_reference():
     c.add_channel("classification", pcr.DataType.Int32)
     with pytest.raises(RuntimeError, match="only Float32 channels supported for filtering"):
         pipe.ingest(c)
-    # output_path: result still produced, GeoTIFF refused
-    cfg = config_for(og, [spec("Sum")], output_path="/tmp/out.tif")
+    # output_path that cannot be created: the result is still produced, the write error surfaces
+    cfg = config_for(og, [spec("Sum")], output_path="/nonexistent-dir/out.tif")
     pipe = pcr.Pipeline.create(cfg)
     pipe.ingest(cloud_from([1.0], [1.0], {"value": [1]}))
-    with pytest.raises(RuntimeError, match="GeoTIFF writing is not part of this build"):
+    with pytest.raises(RuntimeError, match="failed to create GeoTIFF"):
         pipe.finalize()
     assert pipe.result().band_array(0)[9, 1] == 1.0
 
@@ -237,3 +237,40 @@ def test_sharded_pipelines_on_one_gpu_equal_unsharded():
     want_g = O.run(og, O.WEIGHTED_AVERAGE, x, y, v, glyph=O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=2.0, max_radius=5.0))
     assert_band_close(got_g, want_g, rtol=1e-4, atol=1e-6, what="sharded gaussian")
     assert_band_close(got_c, O.run(og, O.COUNT, x, y, v), what="sharded count")
+
+
+@pytest.mark.parametrize("result_on", ["host", "device"])
+def test_file_in_file_out(tmp_path, result_on):
+    """PCRP file -> HBM -> ingest -> finalize -> GeoTIFF at output_path (pipeline.cpp:1351-1361 of the
+    reference), read back and compared with the in-memory result and the oracle."""
+    og = O.make_grid((0.0, 0.0, 200.0, 120.0), tile=(64, 64))
+    rng = np.random.default_rng(21)
+    n = 50_000
+    x, y = rng.uniform(0, 200, n), rng.uniform(0, 120, n)
+    v = rng.normal(5.0, 2.0, n).astype(np.float32)
+    src = str(tmp_path / "in.pcrp")
+    pcr.write_point_cloud(src, cloud_from(x, y, {"value": v}))
+    cloud = pcr.read_point_cloud(src, pcr.PointCloudFormat.Auto, pcr.MemoryLocation.Device)
+    assert cloud.location() == pcr.MemoryLocation.Device and cloud.count() == n
+    out = str(tmp_path / "out.tif")
+    cfg = config_for(og, [spec("Count"), spec("Average")], output_path=out)
+    cfg.grid.crs = pcr.CRS.from_epsg(32633)
+    if result_on == "device":
+        cfg.result_location = pcr.MemoryLocation.Device
+    pipe = pcr.Pipeline.create(cfg)
+    assert pipe is not None, pcr.pipeline_create_error()
+    pipe.ingest(cloud)
+    pipe.finalize()
+    w, h, nb, crs, bounds = pcr.read_geotiff_info(out)
+    assert (w, h, nb) == (200, 120, 2) and crs.epsg == 32633
+    assert (bounds.min_x, bounds.min_y, bounds.max_x, bounds.max_y) == (0.0, 0.0, 200.0, 120.0)
+    res = pipe.result() if result_on == "host" else pipe.result().to_host()
+    for b, name in enumerate(("Count", "Average")):
+        got = pcr.read_geotiff_band(out, b)
+        assert np.array_equal(got, res.band_array(b), equal_nan=True)
+        want = O.run(og, ORT[name], x, y, v)
+        if name == "Count":
+            assert_band_close(got, want, what="Count from file")
+        else:
+            assert_band_close(got, want, rtol=2e-5, atol=1e-4, what="Average from file")
+    assert pcr.read_geotiff_band_names(out) == [res.band_desc(0).name, res.band_desc(1).name]
