@@ -87,7 +87,7 @@ def build_host(force=False):
     hip_so = os.path.join(LIB, "libpcr_hip.so")
     if jobs or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(hip_so):
         run([cxx, "-shared", "-o", out] + objs +
-            ["-L" + LIB, "-lpcr_hip", "-lz", "-Wl,-rpath,$ORIGIN/../../lib", "-Wl,--no-undefined",
+            ["-L" + LIB, "-lpcr_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/../../lib", "-Wl,--no-undefined",
              "-L" + sysconfig.get_config_var("LIBDIR"), "-lpython" + sysconfig.get_config_var("LDVERSION")])
     return out
 

@@ -10,11 +10,14 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <sstream>
+#include <thread>
 
 namespace pcr {
 
@@ -100,12 +103,12 @@ bool lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_n) {
     static thread_local uint16_t prefix[4096];
     static thread_local uint8_t suffix[4096];
     static thread_local uint16_t length[4096];
-    for (int i = 0; i < 256; ++i) { prefix[i] = 0xFFFF; suffix[i] = (uint8_t)i; length[i] = 1; }
+    static thread_local uint8_t first[4096];
+    for (int i = 0; i < 256; ++i) { prefix[i] = 0xFFFF; suffix[i] = (uint8_t)i; length[i] = 1; first[i] = (uint8_t)i; }
     int next = 258, nbits = 9, old = -1;
     uint32_t acc = 0;
     int nacc = 0;
     size_t ip = 0, op = 0;
-    auto first_byte = [&](int code) { while (prefix[code] != 0xFFFF) code = prefix[code]; return suffix[code]; };
     auto emit = [&](int code) -> bool {
         const size_t len = length[code];
         if (op + len > dst_n) return false;
@@ -132,9 +135,9 @@ bool lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t dst_n) {
         }
         if (code < next) {
             if (!emit(code)) return false;
-            if (next < 4096) { prefix[next] = (uint16_t)old; suffix[next] = first_byte(code); length[next] = (uint16_t)(length[old] + 1); ++next; }
+            if (next < 4096) { prefix[next] = (uint16_t)old; suffix[next] = first[code]; first[next] = first[old]; length[next] = (uint16_t)(length[old] + 1); ++next; }
         } else if (code == next && next < 4096) {
-            prefix[next] = (uint16_t)old; suffix[next] = first_byte(old); length[next] = (uint16_t)(length[old] + 1); ++next;
+            prefix[next] = (uint16_t)old; suffix[next] = first[old]; first[next] = first[old]; length[next] = (uint16_t)(length[old] + 1); ++next;
             if (!emit(code)) return false;
         } else {
             return false;
@@ -208,12 +211,46 @@ public:
 
     // Block (bx, by) of `band` from src (top-left of the block's valid part, `stride` floats per row).
     Status write_block(int band, int bx, int by, const float* src, int64_t stride) {
-        const int cols = std::min(spec_.bw, spec_.W - bx * spec_.bw);
-        const int rows = std::min(spec_.bh, spec_.H - by * spec_.bh);
-        const int out_rows = spec_.tiled ? spec_.bh : rows;         // tiles are padded, the last strip is short
-        raw_.assign((size_t)spec_.bw * out_rows, std::nanf(""));
-        for (int r = 0; r < rows; ++r) std::memcpy(&raw_[(size_t)r * spec_.bw], src + (int64_t)r * stride, (size_t)cols * 4);
-        return put_block(((size_t)band * byn_ + by) * bxn_ + bx, reinterpret_cast<const uint8_t*>(raw_.data()), raw_.size() * 4);
+        Status s = pack_block(bx, by, src, stride, raw_, packed_, lzw_);
+        if (!s.ok()) return s;
+        return append_block(((size_t)band * byn_ + by) * bxn_ + bx, packed_);
+    }
+
+    struct Job { int band, bx, by; const float* src; int64_t stride; };
+    // Many blocks: compression runs on worker threads (blocks are independent), the file is appended in order.
+    Status write_blocks(const std::vector<Job>& jobs) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nthreads = spec_.compression == kCompNone ? 1 : std::min<size_t>({(size_t)hw, 32, jobs.size()});
+        if (nthreads <= 1) {
+            for (const Job& j : jobs) { Status s = write_block(j.band, j.bx, j.by, j.src, j.stride); if (!s.ok()) return s; }
+            return Status::success();
+        }
+        const size_t batch = nthreads * 4;
+        std::vector<std::vector<uint8_t>> packed(batch);
+        std::vector<Status> st(batch);
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += batch) {
+            const size_t nb = std::min(batch, jobs.size() - j0);
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                std::vector<float> raw;
+                auto enc = std::make_unique<LzwEncoder>();
+                for (size_t k = next++; k < nb; k = next++) {
+                    const Job& j = jobs[j0 + k];
+                    st[k] = pack_block(j.bx, j.by, j.src, j.stride, raw, packed[k], *enc);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t + 1 < std::min(nthreads, nb); ++t) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+            for (size_t k = 0; k < nb; ++k) {
+                if (!st[k].ok()) return st[k];
+                const Job& j = jobs[j0 + k];
+                Status s = append_block(((size_t)j.band * byn_ + j.by) * bxn_ + j.bx, packed[k]);
+                if (!s.ok()) return s;
+            }
+        }
+        return Status::success();
     }
 
     Status close() {
@@ -227,7 +264,8 @@ public:
             const int kind = rows == spec_.bh ? 0 : 1;
             if (!fill_off[kind]) {
                 raw_.assign((size_t)spec_.bw * rows, std::nanf(""));
-                Status s = put_block(i, reinterpret_cast<const uint8_t*>(raw_.data()), raw_.size() * 4);
+                Status s = compress_bytes(reinterpret_cast<const uint8_t*>(raw_.data()), raw_.size() * 4, packed_, lzw_);
+                if (s.ok()) s = append_block(i, packed_);
                 if (!s.ok()) return s;
                 fill_off[kind] = offsets_[i];
                 fill_cnt[kind] = counts_[i];
@@ -264,27 +302,39 @@ private:
         return Status::success();
     }
 
-    Status put_block(size_t index, const uint8_t* bytes, size_t n) {
-        const uint8_t* out = bytes;
-        size_t out_n = n;
+    // thread-safe: touches only its arguments and the (constant) spec
+    Status pack_block(int bx, int by, const float* src, int64_t stride, std::vector<float>& raw,
+                      std::vector<uint8_t>& out, LzwEncoder& enc) const {
+        const int cols = std::min(spec_.bw, spec_.W - bx * spec_.bw);
+        const int rows = std::min(spec_.bh, spec_.H - by * spec_.bh);
+        const int out_rows = spec_.tiled ? spec_.bh : rows;         // tiles are padded, the last strip is short
+        raw.assign((size_t)spec_.bw * out_rows, std::nanf(""));
+        for (int r = 0; r < rows; ++r) std::memcpy(&raw[(size_t)r * spec_.bw], src + (int64_t)r * stride, (size_t)cols * 4);
+        return compress_bytes(reinterpret_cast<const uint8_t*>(raw.data()), raw.size() * 4, out, enc);
+    }
+
+    Status compress_bytes(const uint8_t* bytes, size_t n, std::vector<uint8_t>& out, LzwEncoder& enc) const {
+        out.clear();
         if (spec_.compression == kCompLzw) {
-            packed_.clear();
-            lzw_.encode(bytes, n, packed_);
-            out = packed_.data();
-            out_n = packed_.size();
+            enc.encode(bytes, n, out);
         } else if (spec_.compression == kCompDeflate) {
             uLongf cap = compressBound((uLong)n);
-            packed_.resize(cap);
-            if (compress2(packed_.data(), &cap, bytes, (uLong)n, spec_.level) != Z_OK)
+            out.resize(cap);
+            if (compress2(out.data(), &cap, bytes, (uLong)n, spec_.level) != Z_OK)
                 return Status::error(StatusCode::IoError, "failed to compress GeoTIFF block");
-            out = packed_.data();
-            out_n = cap;
+            out.resize(cap);
+        } else {
+            out.assign(bytes, bytes + n);
         }
-        if (!spec_.big && pos_ + out_n > 0xFFFFFFF0ull)
+        return Status::success();
+    }
+
+    Status append_block(size_t index, const std::vector<uint8_t>& bytes) {
+        if (!spec_.big && pos_ + bytes.size() > 0xFFFFFFF0ull)
             return Status::error(StatusCode::IoError, "GeoTIFF larger than 4 GB needs options.bigtiff");
         offsets_[index] = pos_;
-        counts_[index] = out_n;
-        return put_bytes(out, out_n);
+        counts_[index] = bytes.size();
+        return put_bytes(bytes.data(), bytes.size());
     }
 
     void add_shorts(std::vector<TagOut>& t, uint16_t tag, const std::vector<uint16_t>& v) {
@@ -588,15 +638,15 @@ Status write_geotiff(const std::string& path, const Grid& grid, const GridConfig
     TiffOut out;
     if (!(s = out.open(path, spec, config, names)).ok()) return s;
     const int bxn = (spec.W + spec.bw - 1) / spec.bw, byn = (spec.H + spec.bh - 1) / spec.bh;
+    std::vector<TiffOut::Job> jobs;
     for (int b = 0; b < grid.num_bands(); ++b) {
         const float* band = grid.band_f32(b);
         if (!band) return Status::error(StatusCode::IoError, "failed to get band " + std::to_string(b));
         for (int by = 0; by < byn; ++by)
-            for (int bx = 0; bx < bxn; ++bx) {
-                s = out.write_block(b, bx, by, band + (int64_t)by * spec.bh * spec.W + (int64_t)bx * spec.bw, spec.W);
-                if (!s.ok()) return s;
-            }
+            for (int bx = 0; bx < bxn; ++bx)
+                jobs.push_back({b, bx, by, band + (int64_t)by * spec.bh * spec.W + (int64_t)bx * spec.bw, spec.W});
     }
+    if (!(s = out.write_blocks(jobs)).ok()) return s;
     return out.close();
 }
 
