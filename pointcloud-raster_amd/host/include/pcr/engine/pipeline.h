@@ -89,6 +89,13 @@ public:
 
     Status validate() const;
     Status ingest(const PointCloud& cloud);
+    /// Extension: like ingest, but returns once the work is enqueued when the cloud is
+    /// page-locked (HostPinned) or device-resident; the cloud must stay untouched until synchronize() /
+    /// finalize().  Pageable host clouds behave as in ingest.
+    Status ingest_async(const PointCloud& cloud);
+    /// Extension: streams a PCRP / CSV file through two page-locked chunk buffers -- the file read of chunk
+    /// k+1 overlaps the host-to-device copy and the kernels of chunk k.  `points_read` (optional) = rows read.
+    Status ingest_file(const std::string& path, size_t chunk_points = 4u << 20, size_t* points_read = nullptr);
     Status finalize();
     Status run(const std::vector<const PointCloud*>& clouds);
     void set_progress_callback(ProgressCallback cb);

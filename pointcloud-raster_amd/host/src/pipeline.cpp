@@ -15,6 +15,7 @@
 #include "pcr/core/grid.h"
 #include "pcr/core/point_cloud.h"
 #include "pcr/io/grid_io.h"
+#include "pcr/io/point_cloud_io.h"
 #include "pcr/io/tile_state_io.h"
 
 #include <algorithm>
@@ -237,7 +238,7 @@ struct Pipeline::Impl {
         return Status::success();
     }
 
-    Status ingest(const PointCloud& cloud) {
+    Status ingest(const PointCloud& cloud, bool wait = true) {
         const size_t n = cloud.count();
         if (n == 0) return Status::success();
         // filter predicates: same checks and messages as filter_points (src/engine/filter.cpp:101-123)
@@ -357,8 +358,9 @@ struct Pipeline::Impl {
             }
             if (!s.ok()) return s;
         }
-        // host arrays may be reused by the caller as soon as we return
-        if (loc != MemoryLocation::Device) {
+        // host arrays may be reused by the caller as soon as we return (ingest_async: page-locked arrays are
+        // read by the DMA engine later, the caller keeps them alive until synchronize())
+        if (loc != MemoryLocation::Device && (wait || loc != MemoryLocation::HostPinned)) {
             s = detail::hip_status(pcr_hip_stream_synchronize(stream));
             if (!s.ok()) return s;
         }
@@ -668,6 +670,31 @@ Status Pipeline::validate() const {
 }
 
 Status Pipeline::ingest(const PointCloud& cloud) { return impl_->ingest(cloud); }
+Status Pipeline::ingest_async(const PointCloud& cloud) { return impl_->ingest(cloud, false); }
+
+Status Pipeline::ingest_file(const std::string& path, size_t chunk_points, size_t* points_read) {
+    if (points_read) *points_read = 0;
+    if (chunk_points == 0) return Status::error(StatusCode::InvalidArgument, "pipeline: chunk_points must be positive");
+    auto reader = PointCloudReader::open(path);
+    if (!reader) return Status::error(StatusCode::IoError, "pipeline: failed to open point cloud file: " + path);
+    chunk_points = std::min(chunk_points, std::max<size_t>(reader->info().num_points, 1));
+    std::unique_ptr<PointCloud> buf[2] = {PointCloud::create(chunk_points, MemoryLocation::HostPinned),
+                                          PointCloud::create(chunk_points, MemoryLocation::HostPinned)};
+    if (!buf[0] || !buf[1]) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate page-locked chunk buffers");
+    size_t total = 0;
+    int cur = 0;
+    size_t got = reader->read_chunk(*buf[cur], chunk_points);
+    while (got > 0) {
+        Status s = ingest_async(*buf[cur]);              // H2D + kernels of this chunk, enqueued
+        if (!s.ok()) { (void)synchronize(); return s; }
+        total += got;
+        got = reader->read_chunk(*buf[cur ^ 1], chunk_points);   // overlaps with them
+        if (!(s = synchronize()).ok()) return s;         // buf[cur] is free again
+        cur ^= 1;
+    }
+    if (points_read) *points_read = total;
+    return Status::success();
+}
 Status Pipeline::finalize() { return impl_->finalize(); }
 
 Status Pipeline::run(const std::vector<const PointCloud*>& clouds) {

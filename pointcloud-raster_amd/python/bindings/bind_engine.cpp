@@ -114,6 +114,17 @@ void bind_engine(py::module_& m) {
         .def_static("create", &Pipeline::create)      // None on failure; reason: pcr.pipeline_create_error()
         .def("validate", [](const Pipeline& p) { raise_if_error(p.validate()); })
         .def("ingest", [](Pipeline& p, const PointCloud& c) { raise_if_error(p.ingest(c)); })
+        .def("ingest_async", [](Pipeline& p, const PointCloud& c) { raise_if_error(p.ingest_async(c)); }, py::arg("cloud"),
+             "ingest without waiting when the cloud is page-locked or device-resident (keep it alive until synchronize())")
+        .def("ingest_file", [](Pipeline& p, const std::string& path, size_t chunk_points) {
+            size_t n = 0;
+            {
+                py::gil_scoped_release release;
+                raise_if_error(p.ingest_file(path, chunk_points, &n));
+            }
+            return n;
+        }, py::arg("path"), py::arg("chunk_points") = size_t(4) << 20,
+             "stream a PCRP / CSV file through page-locked double buffers; returns the number of points read")
         .def("finalize", [](Pipeline& p) { raise_if_error(p.finalize()); })
         .def("run", [](Pipeline& p, const std::vector<const PointCloud*>& cs) { raise_if_error(p.run(cs)); })
         .def("set_progress_callback", &Pipeline::set_progress_callback)

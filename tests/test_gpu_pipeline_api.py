@@ -274,3 +274,38 @@ def test_file_in_file_out(tmp_path, result_on):
         else:
             assert_band_close(got, want, rtol=2e-5, atol=1e-4, what="Average from file")
     assert pcr.read_geotiff_band_names(out) == [res.band_desc(0).name, res.band_desc(1).name]
+
+
+def test_ingest_file_streams_chunks_and_ingest_async():
+    """Double-buffered file streaming equals one ingest of the whole cloud."""
+    import os
+    import tempfile
+    og = O.make_grid((0.0, 0.0, 256.0, 128.0))
+    rng = np.random.default_rng(33)
+    n = 300_000
+    x, y = rng.uniform(-1, 257, n), rng.uniform(-1, 129, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    whole = cloud_from(x, y, {"value": v})
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "s.pcrp")
+        pcr.write_point_cloud(path, whole)
+        pipe = pcr.Pipeline.create(config_for(og, [spec("Count"), spec("Max")]))
+        assert pipe.ingest_file(path, chunk_points=47_000) == n          # 7 chunks, the last one ragged
+        pipe.finalize()
+        assert pipe.stats().points_processed == n
+        with pytest.raises(RuntimeError, match="failed to open point cloud file"):
+            pipe.ingest_file(os.path.join(d, "missing.pcrp"))
+    np.testing.assert_array_equal(pipe.result().band_array(0), O.run(og, O.COUNT, x, y, v))
+    np.testing.assert_array_equal(pipe.result().band_array(1), O.run(og, O.MAX, x, y, v))
+    # ingest_async on page-locked chunks: nothing is waited for until finalize
+    pipe2 = pcr.Pipeline.create(config_for(og, [spec("Count")]))
+    halves = []
+    for sl in (slice(0, n // 2), slice(n // 2, n)):
+        c = pcr.PointCloud.create(n, pcr.MemoryLocation.HostPinned)
+        c.set_x_array(x[sl]); c.set_y_array(y[sl])
+        c.add_channel("value", pcr.DataType.Float32)
+        c.set_channel_array_f32("value", v[sl])
+        halves.append(c)
+        pipe2.ingest_async(c)
+    pipe2.finalize()
+    np.testing.assert_array_equal(pipe2.result().band_array(0), O.run(og, O.COUNT, x, y, v))

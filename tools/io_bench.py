@@ -26,6 +26,30 @@ for loc, name in ((pcr.MemoryLocation.Host, "Host"), (pcr.MemoryLocation.HostPin
         t = time.perf_counter(); c = pcr.read_point_cloud(p, pcr.PointCloudFormat.Auto, loc); dt = time.perf_counter() - t
         del c
     print(f"PCRP read -> {name:10s} {dt*1e3:8.1f} ms  {gb/dt:6.2f} GB/s   (page cache warm)")
+# file -> finalized grid, two ways (C2 reductions on 4096^2)
+def pipeline():
+    c = pcr.PipelineConfig()
+    c.grid.bounds = pcr.BBox(0.0, 0.0, 4096.0, 4096.0); c.grid.cell_size_x, c.grid.cell_size_y = 1.0, -1.0
+    c.grid.compute_dimensions(); c.exec_mode = pcr.ExecutionMode.GPU
+    specs = []
+    for t in (pcr.ReductionType.Sum, pcr.ReductionType.Count, pcr.ReductionType.Average):
+        r = pcr.ReductionSpec(); r.value_channel, r.type = "value", t; specs.append(r)
+    c.reductions = specs
+    c.result_location = pcr.MemoryLocation.Device
+    return pcr.Pipeline.create(c)
+for rep in range(2):
+    pp = pipeline()
+    t = time.perf_counter()
+    c = pcr.read_point_cloud(p, pcr.PointCloudFormat.Auto, pcr.MemoryLocation.Device); pp.ingest(c); pp.finalize()
+    dt_whole = time.perf_counter() - t
+    del c, pp
+for chunk in (4 << 20, 16 << 20):
+    for rep in range(2):
+        pp = pipeline()
+        t = time.perf_counter(); got = pp.ingest_file(p, chunk); pp.finalize(); dt = time.perf_counter() - t
+        del pp
+    print(f"file -> grid, ingest_file chunk {chunk>>20:3d} M pts: {dt*1e3:8.1f} ms  {n/dt/1e6:7.1f} Mpts/s   ({got} points)")
+print(f"file -> grid, read whole to HBM then ingest: {dt_whole*1e3:8.1f} ms  {n/dt_whole/1e6:7.1f} Mpts/s")
 W = H = 4096
 bands = []
 for nm in ("sum", "count", "avg"):
