@@ -88,18 +88,20 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         const double2* y2 = reinterpret_cast<const double2*>(y + base);
         const float2* v2 = reinterpret_cast<const float2*>(v + base);
         uint2* k2 = reinterpret_cast<uint2*>(keys + base);
-        const int pairs = b.chunk >> 1;                          // chunk = 8192: exactly one trip
+        const int pairs = b.chunk >> 1;                          // 4096 or 2048 pairs: one trip, 4 or 2 loads per array
         for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kThreads) {
             double2 xs[4], ys[4];
             float2 vs[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (p0 + u * kThreads >= pairs) break;           // uniform
                 xs[u] = x2[p0 + u * kThreads];
                 ys[u] = y2[p0 + u * kThreads];
                 vs[u] = v2[p0 + u * kThreads];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (p0 + u * kThreads >= pairs) break;
                 const uint64_t i = base + 2ull * (p0 + u * kThreads);
                 unsigned ka = handle(i, xs[u].x, ys[u].x, vs[u].x);
                 unsigned kb = handle(i + 1, xs[u].y, ys[u].y, vs[u].y);
@@ -150,8 +152,9 @@ k_mom_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restri
 }
 
 // ---- pass B: 16-byte records {local cell, value, s'x, s'y}, grouped by bin ---------------------------
-constexpr int kScatterPer = 8;         // 8192-point chunks: 128 KB of staging
+// points per thread: 8 (8192-point chunks, 128 KB of staging, up to 2560 tiles) or 4 (4096-point chunks, up to 8064 tiles)
 
+template <int kScatterPer>
 __global__ void __launch_bounds__(kThreads)
 k_mom_scatter(GridDev g, BinGeom b, const unsigned* __restrict__ keys, const double* __restrict__ x,
               const double* __restrict__ y, const float* __restrict__ v, uint64_t n,
@@ -724,10 +727,10 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     p.bins.bins_x = (g.W + kTileW - 1) / kTileW;
     p.bins.bins_y = (g.st_rows + kTileH - 1) / kTileH;
     p.bins.nbins = p.bins.bins_x * p.bins.bins_y;
-    p.bins.chunk = kScatterPer * kThreads;
+    p.bins.chunk = (p.bins.nbins <= 2560 ? 8 : 4) * kThreads;
     p.bins.row0 = 0;
     p.bins.rows = g.st_rows;
-    if (p.bins.nbins > 2560) return false;                             // scatter staging: 128 KB + 12 B per bin
+    if (p.bins.nbins > kMaxBins) return false;                         // scatter staging: 16 B x chunk + 12 B per bin of LDS
     *out = p;
     return true;
 }
@@ -847,10 +850,12 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     {
         ScopedKernelTimer t(e, "k_mom_scatter");
         const size_t lds = (size_t)b.chunk * 16 + (size_t)b.nbins * 12;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mom_scatter),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_mom_scatter, dim3(blocks), dim3(kThreads), lds, e->stream, g, b, d_keys, x, y, v, n,
-                           d_cursor, d_rec);
+        auto launch = [&](auto kernel) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds, e->stream, g, b, d_keys, x, y, v, n, d_cursor, d_rec);
+        };
+        if (b.chunk == 8 * kThreads) launch(&k_mom_scatter<8>);
+        else launch(&k_mom_scatter<4>);
     }
     {
         ScopedKernelTimer t(e, "k_tile_moments");
