@@ -28,12 +28,15 @@ def run_gpu(A, og, rtype, x, y, v, gl, path, own_rows=None, halo=0):
         raise
 
 
-def check(got, want, exact, what):
+def check(got, want, exact, what, scale=1.0):
+    """rtol 1e-4 with a floor of 1e-3 of the data scale (a weighted average of values ~10 that happens to land
+    within 1e-3 of zero cannot be asked for 1e-7 absolute: that is below one float32 ulp of its terms; the
+    reference's own CPU<->GPU criterion is 1e-4 ABSOLUTE, scripts/patterns/compare_cpu_gpu_patterns.py:28,92)."""
     assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN mask"
     m = ~np.isnan(want)
     err = np.abs(got[m].astype(np.float64) - exact[m])
-    tol = 1e-4 * np.maximum(1e-3, np.abs(exact[m]))
-    assert (err <= tol).all(), f"{what}: max rel err {np.max(err / np.maximum(1e-3, np.abs(exact[m]))):.3e}"
+    ref = np.maximum(1e-3 * scale, np.abs(exact[m]))
+    assert (err <= 1e-4 * ref).all(), f"{what}: max rel err {np.max(err / ref):.3e}"
 
 
 CASES = [
@@ -77,7 +80,7 @@ def test_moment_path_matches_oracle(A, case, rname):
     ref = O.Reduction(og, rt, ogl)
     ref.ingest(x, y, v)
     assert st.points_valid == ref.points_valid()
-    check(got, want, exact, f'{case["name"]}/{rname}')
+    check(got, want, exact, f'{case["name"]}/{rname}', scale=1.0 if rname == "Count" else 10.0)   # v ~ N(10, 3)
 
 
 def test_moment_path_nonfinite_values_and_second_ingest(A):
