@@ -19,7 +19,8 @@ struct pcr_hip_engine {
 
     int forced_path = 0;                       // 0 auto, 1 direct, 2 binned, 3 moments (Gaussian only)
     int max_bins = 0;                          // LDS tiles per binning pass (kMaxBins; PCR_HIP_DEBUG_MAX_BINS lowers it
-                                               // so that tests reach the row-band sweep on small grids)
+                                               // so that tests reach the large-grid paths on small grids)
+    bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
     pcr_hip_scatter_stats stats{};
 
     // optional per-kernel event timing
@@ -62,6 +63,7 @@ struct BinGeom {
     int bins_x, bins_y, nbins;
     int chunk;                          // points per workgroup in the count / scatter passes
     int row0, rows;                     // the band of state rows [row0, row0 + rows) the bins cover (window-relative)
+    int sup_shift;                      // two-level sort: the first level groups 2^sup_shift consecutive tiles (0: one level)
 };
 constexpr int kMaxBands = 32;           // a grid with more LDS tiles than kMaxBins is swept in row bands
 struct BinItem {                        // one workgroup's share of a bin's records
@@ -81,6 +83,8 @@ struct BinBuffers {                     // device pointers into the engine's scr
 };
 constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 12 B per bin <= 160 KB
 constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
+constexpr int kMaxTiles = 1 << (32 - kLcellBits);   // routing key = tile << 15 | local cell
+constexpr int kMaxSubBins = 2048;       // tiles per first-level group (second-level scatter: 128 KB staging + 12 B per tile)
 
 // Rows per band so that a band's bins fit the binning passes (whole tile rows); 0 = cannot be banded.
 inline int band_rows_for(const GridDev& g, int tile_w, int tile_h, int max_bins) {

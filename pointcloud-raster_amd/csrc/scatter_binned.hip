@@ -62,7 +62,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
         Routed r = route(g, b, wx, wy);
         if (r.valid && point_kept(g, i)) {
-            atomicAdd(&lds_hist[r.bin], 1u);
+            atomicAdd(&lds_hist[r.bin >> b.sup_shift], 1u);
             ++my_valid;
             if (!one_tile) touch_tile(g, touched, r.row, r.col);
             return ((unsigned)r.bin << kLcellBits) | r.lcell;
@@ -173,6 +173,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
 
     for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
     __syncthreads();
+    const int gshift = kLcellBits + b.sup_shift;          // key -> bin of this pass (a tile, or a group of tiles)
 
     const uint64_t base = (uint64_t)(blockIdx.x + first_block) * b.chunk;
     unsigned key[PER_THREAD], rank[PER_THREAD], val[PER_THREAD];
@@ -208,7 +209,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
         rank[k] = 0;
-        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);   // rank inside (block, bin)
+        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> gshift], 1u);       // rank inside (block, bin)
     }
     __syncthreads();
 
@@ -243,7 +244,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
         if (key[k] != 0xFFFFFFFFu) {
-            unsigned bin = key[k] >> kLcellBits;
+            unsigned bin = key[k] >> gshift;
             stage[loff[bin] + rank[k]] = make_uint2(key[k], val[k]);
         }
     }
@@ -252,9 +253,100 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     // write out: consecutive staged records of a bin go to consecutive global slots
     for (unsigned j = threadIdx.x; j < total; j += kThreads) {
         uint2 rec = stage[j];
-        unsigned bin = rec.x >> kLcellBits;
+        unsigned bin = rec.x >> gshift;
         unsigned dst = gbase[bin] + (j - loff[bin]);
-        records[dst] = make_uint2(rec.x & kLcellMask, rec.y);
+        records[dst] = make_uint2(b.sup_shift ? rec.x : rec.x & kLcellMask, rec.y);   // first of two levels: keep the tile
+    }
+}
+
+// ---- second level of the two-level sort (grids with more tiles than one pass can count in LDS) ----
+// After the first level the records {tile << 15 | local cell, value} are grouped by GROUP of 2^sup_shift
+// consecutive tiles; a work item is at most 16384 records of one group.  k_sub_count histograms an item by
+// tile, k_bin_scan turns the tile counts into starts, k_sub_scatter sorts the item by tile through LDS and
+// writes {local cell, value} runs -- the same three steps as the first level, on 8-byte records instead of
+// x, y.  Both levels write long runs (16384 / groups, 16384 / tiles-per-group records), where the row-band
+// sweep scattered single records.
+constexpr int kSubPer = 16;                       // records per thread: items of 16384
+
+__global__ void __launch_bounds__(kThreads)
+k_sub_count(int sup_shift, const uint2* __restrict__ rec, const BinItem* __restrict__ items,
+            const unsigned* __restrict__ n_items, unsigned* __restrict__ tile_count) {
+    extern __shared__ unsigned lds_u32[];
+    if (blockIdx.x >= *n_items) return;
+    const BinItem it = items[blockIdx.x];
+    const int tps = 1 << sup_shift;
+    for (int i = threadIdx.x; i < tps; i += kThreads) lds_u32[i] = 0;
+    __syncthreads();
+    const unsigned tile0 = it.bin << sup_shift;
+    const uint2* r = rec + it.first;
+    for (unsigned j = threadIdx.x; j < it.count; j += kThreads) atomicAdd(&lds_u32[(r[j].x >> kLcellBits) - tile0], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < tps; i += kThreads) {
+        const unsigned c = lds_u32[i];
+        if (c) atomicAdd(&tile_count[tile0 + i], c);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sub_scatter(int sup_shift, const uint2* __restrict__ rec, const BinItem* __restrict__ items,
+              const unsigned* __restrict__ n_items, unsigned* __restrict__ cursor, uint2* __restrict__ out) {
+    extern __shared__ unsigned char lds_raw[];
+    if (blockIdx.x >= *n_items) return;
+    const BinItem it = items[blockIdx.x];
+    const int tps = 1 << sup_shift;
+    // layout: stage[16384] (8 B each) | hist[tps] | loff[tps] | gbase[tps]
+    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
+    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)kSubPer * kThreads * sizeof(uint2));
+    unsigned* loff = hist + tps;
+    unsigned* gbase = loff + tps;
+    __shared__ unsigned wave_tot[kThreads / 64];
+    for (int i = threadIdx.x; i < tps; i += kThreads) hist[i] = 0;
+    __syncthreads();
+    const unsigned tile0 = it.bin << sup_shift;
+    const uint2* r = rec + it.first;
+    uint2 rc[kSubPer];
+    unsigned rank[kSubPer];
+#pragma unroll
+    for (int k = 0; k < kSubPer; ++k) {
+        const unsigned j = k * kThreads + threadIdx.x;
+        rc[k] = j < it.count ? r[j] : make_uint2(0xFFFFFFFFu, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < kSubPer; ++k) {
+        rank[k] = 0;
+        if (rc[k].x != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[(rc[k].x >> kLcellBits) - tile0], 1u);
+    }
+    __syncthreads();
+    const int per = (tps + kThreads - 1) / kThreads;            // <= 2
+    const int lo = threadIdx.x * per, hi = min(lo + per, tps);
+    unsigned s = 0;
+    for (int i = lo; i < hi; ++i) s += hist[i];
+    unsigned incl = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - s;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    for (int i = lo; i < hi; ++i) {
+        const unsigned c = hist[i];
+        loff[i] = run;
+        if (c) gbase[i] = atomicAdd(&cursor[tile0 + i], c);
+        run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSubPer; ++k)
+        if (rc[k].x != 0xFFFFFFFFu) stage[loff[(rc[k].x >> kLcellBits) - tile0] + rank[k]] = rc[k];
+    __syncthreads();
+    for (unsigned j = threadIdx.x; j < it.count; j += kThreads) {
+        const uint2 q = stage[j];
+        const unsigned t = (q.x >> kLcellBits) - tile0;
+        out[gbase[t] + (j - loff[t])] = make_uint2(q.x & kLcellMask, q.y);
     }
 }
 
@@ -348,6 +440,7 @@ inline BinGeom point_bin_geom(const GridDev& g, uint32_t mask, int row0, int row
     b.chunk = b.nbins <= 2048 ? 16384 : 8192;
     b.row0 = row0;
     b.rows = rows;
+    b.sup_shift = 0;
     return b;
 }
 
@@ -551,6 +644,100 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     return PCR_HIP_OK;
 }
 
+// Two-level counting sort for the Point glyph on grids with more LDS tiles than one pass can count
+// (16384^2 = 21 888 tiles): level 1 groups the points by runs of 2^s consecutive tiles (about sqrt(tiles)
+// groups), level 2 sorts every group by tile.  Both levels stream; see k_sub_count / k_sub_scatter.
+int two_level_shift(const pcr_hip_engine* e, int tiles) {
+    if (!e->two_level || tiles > kMaxTiles) return 0;
+    int s = 1;
+    while ((1 << (2 * s)) < tiles) ++s;                                  // groups ~ tiles per group ~ sqrt(tiles)
+    while (((tiles + (1 << s) - 1) >> s) > e->max_bins) ++s;
+    return (1 << s) <= kMaxSubBins ? s : 0;
+}
+
+int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* x, const double* y, const float* v,
+                         uint64_t n, unsigned item_records, BinBuffers* out) {
+    BinGeom l1 = tiles;                                                   // first level: groups of tiles
+    l1.nbins = (tiles.nbins + (1 << tiles.sup_shift) - 1) >> tiles.sup_shift;
+    l1.chunk = l1.nbins <= 2048 ? 16384 : 8192;
+    const unsigned sub_records = kSubPer * kThreads;
+    const int blocks = (int)((n + l1.chunk - 1) / l1.chunk);
+    const int max_items1 = l1.nbins + (int)(n / sub_records) + 1;
+    const int max_items2 = tiles.nbins + (int)(n / item_records) + 1;
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+    const size_t o_count1 = carve((size_t)l1.nbins * 4), o_cursor1 = carve((size_t)l1.nbins * 4), o_nitems1 = carve(4);
+    const size_t o_items1 = carve((size_t)max_items1 * sizeof(BinItem));
+    const size_t o_count2 = carve((size_t)tiles.nbins * 4), o_cursor2 = carve((size_t)tiles.nbins * 4), o_nitems2 = carve(4);
+    const size_t o_items2 = carve((size_t)max_items2 * sizeof(BinItem));
+    const size_t o_keys = carve((size_t)n * 4), o_rec1 = carve((size_t)n * 8), o_rec2 = carve((size_t)n * 8);
+    int rc = ensure_scratch(e, off);
+    if (rc) return rc;
+    char* s = e->d_scratch;
+    auto U = [&](size_t o) { return reinterpret_cast<unsigned*>(s + o); };
+    BinItem* d_items1 = reinterpret_cast<BinItem*>(s + o_items1);
+    BinItem* d_items2 = reinterpret_cast<BinItem*>(s + o_items2);
+    uint2* d_rec1 = reinterpret_cast<uint2*>(s + o_rec1);
+    uint2* d_rec2 = reinterpret_cast<uint2*>(s + o_rec2);
+
+    PCR_HIP_TRY(hipMemsetAsync(U(o_count1), 0, (size_t)l1.nbins * 4, e->stream));
+    PCR_HIP_TRY(hipMemsetAsync(U(o_count2), 0, (size_t)tiles.nbins * 4, e->stream));
+    {
+        ScopedKernelTimer t(e, "k_bin_count");
+        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kThreads), (size_t)l1.nbins * 4, e->stream,
+                           e->gd, l1, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+    }
+    {
+        ScopedKernelTimer t(e, "k_bin_scan");
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, l1.nbins, sub_records, U(o_count1),
+                           U(o_cursor1), d_items1, U(o_nitems1));
+    }
+    {
+        ScopedKernelTimer t(e, "k_bin_scatter");
+        const size_t lds = (size_t)l1.chunk * sizeof(uint2) + (size_t)l1.nbins * 4 * 3;
+        const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+        const int full_blocks = aligned ? (int)(n / l1.chunk) : 0;
+        auto launch = [&](auto kernel, int nblocks, int first) {
+            if (nblocks <= 0) return;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, l1, first, U(o_keys), v, n, U(o_cursor1), d_rec1);
+        };
+        if (l1.chunk == 16384) {
+            launch(&k_bin_scatter<16, true, false>, full_blocks, 0);
+            launch(&k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
+        } else {
+            launch(&k_bin_scatter<8, true, false>, full_blocks, 0);
+            launch(&k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
+        }
+    }
+    const int tps = 1 << tiles.sup_shift;
+    {
+        ScopedKernelTimer t(e, "k_sub_count");
+        hipLaunchKernelGGL(k_sub_count, dim3(max_items1), dim3(kThreads), (size_t)tps * 4, e->stream, tiles.sup_shift,
+                           d_rec1, d_items1, U(o_nitems1), U(o_count2));
+    }
+    {
+        ScopedKernelTimer t(e, "k_bin_scan");
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, tiles.nbins, item_records, U(o_count2),
+                           U(o_cursor2), d_items2, U(o_nitems2));
+    }
+    {
+        ScopedKernelTimer t(e, "k_sub_scatter");
+        const size_t lds = (size_t)sub_records * sizeof(uint2) + (size_t)tps * 4 * 3;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sub_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sub_scatter, dim3(max_items1), dim3(kThreads), lds, e->stream, tiles.sup_shift, d_rec1, d_items1,
+                           U(o_nitems1), U(o_cursor2), d_rec2);
+    }
+    PCR_HIP_TRY(hipGetLastError());
+    out->records = d_rec2;
+    out->grecords = nullptr;
+    out->items = d_items2;
+    out->n_items = U(o_nitems2);
+    out->max_items = max_items2;
+    return PCR_HIP_OK;
+}
+
 // Bands of state rows, each with at most kMaxBins LDS tiles; every band is a full pass over the points
 // (routing keys are cheap: 5 ps per point and band) that only keeps the points of its rows.
 static int point_bands(const pcr_hip_engine* e, uint32_t mask, int* band_rows) {
@@ -565,7 +752,8 @@ bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask) {
     if (mask == 0 || (mask & ~15u)) return false;
     int band_rows = 0;
     const int nbands = point_bands(e, mask, &band_rows);
-    if (nbands < 1 || nbands > kMaxBands) return false;
+    const bool two_level = nbands != 1 && two_level_shift(e, point_bin_geom(e->gd, mask, 0, e->gd.st_rows).nbins) > 0;
+    if (!two_level && (nbands < 1 || nbands > kMaxBands)) return false;
     // not worth the fixed cost of sweeping every tile for a handful of points
     uint64_t cells = (uint64_t)e->gd.W * e->gd.st_rows;
     if (e->forced_path != 2 && e->stats.points_in * 16 < cells) return false;
@@ -575,10 +763,28 @@ bool binned_point_supported(const pcr_hip_engine* e, uint32_t mask) {
 int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n) {
     int band_rows = 0;
-    const int nbands = point_bands(e, mask, &band_rows);
-    if (nbands < 1) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: grid cannot be binned");
+    int nbands = point_bands(e, mask, &band_rows);
     int total_bins = 0;
-    BinGeom b{};
+    BinGeom b = point_bin_geom(e->gd, mask, 0, e->gd.st_rows);
+    const int shift = nbands != 1 ? two_level_shift(e, b.nbins) : 0;
+    if (shift > 0) {                                            // one sweep, two sort levels
+        b.sup_shift = shift;
+        BinBuffers bb{};
+        int rc = bin_points_two_level(e, b, x, y, v, n, kPointItemRecords, &bb);
+        if (rc) return rc;
+        ScopedKernelTimer t(e, "k_tile_accum");
+        switch (mask) {
+#define PCR_ACC(M) case M: launch_accum<M>(e, e->gd, b, pl, bb); break;
+            PCR_ACC(1) PCR_ACC(2) PCR_ACC(3) PCR_ACC(4) PCR_ACC(5) PCR_ACC(6) PCR_ACC(7) PCR_ACC(8)
+            PCR_ACC(9) PCR_ACC(10) PCR_ACC(11) PCR_ACC(12) PCR_ACC(13) PCR_ACC(14) PCR_ACC(15)
+#undef PCR_ACC
+            default: return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: empty plane mask");
+        }
+        total_bins = b.nbins;
+        nbands = 0;
+    } else if (nbands < 1) {
+        return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: grid cannot be binned");
+    }
     for (int band = 0; band < nbands; ++band) {
         const int row0 = band * band_rows, rows = std::min(band_rows, e->gd.st_rows - row0);
         GridDev gd = e->gd;                                     // this band's points only

@@ -229,6 +229,7 @@ bool glyph_tile(const pcr_hip_engine* e, const GlyphDev& gl, unsigned mask, Glyp
     *band_rows = band_rows_for(g, S, S, e->max_bins);
     t.bins.row0 = 0;
     t.bins.rows = g.st_rows;
+    t.bins.sup_shift = 0;
     t.bins.bins_y = (g.st_rows + S - 1) / S;
     t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
     t.bins.chunk = t.bins.nbins <= 2048 ? 16384 : 8192;

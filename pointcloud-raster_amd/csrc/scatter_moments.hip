@@ -730,6 +730,7 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     p.bins.chunk = (p.bins.nbins <= 2560 ? 8 : 4) * kThreads;
     p.bins.row0 = 0;
     p.bins.rows = g.st_rows;
+    p.bins.sup_shift = 0;
     if (p.bins.nbins > kMaxBins) return false;                         // scatter staging: 16 B x chunk + 12 B per bin of LDS
     *out = p;
     return true;

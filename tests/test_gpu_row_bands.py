@@ -1,7 +1,8 @@
-"""Row-band sweep of the binned paths: a grid with more LDS tiles than one binning pass takes is
-processed band by band (scatter_binned.hip / scatter_binned_glyph.hip).  PCR_HIP_DEBUG_MAX_BINS lowers
-the per-pass limit (8064) so that the sweep is reached on grids the oracle finishes in seconds; the
-same bars as everywhere else apply (Count/Min/Max bit-exact, sums 1e-5, glyphs rtol 1e-4)."""
+"""Grids with more LDS tiles than one binning pass takes: the Point glyph sorts in two levels (groups of
+tiles, then tiles), glyphs -- and the Point glyph beyond 131072 tiles -- are swept in row bands
+(scatter_binned.hip / scatter_binned_glyph.hip).  PCR_HIP_DEBUG_MAX_BINS lowers the per-pass limit (8064)
+so that both are reached on grids the oracle finishes in seconds; PCR_HIP_DEBUG_TWO_LEVEL=0 forces the bands.
+The same bars as everywhere else apply (Count/Min/Max bit-exact, sums 1e-5, glyphs rtol 1e-4)."""
 import numpy as np
 import pytest
 
@@ -38,8 +39,10 @@ def run_gpu(A, og, rtype, x, y, v, glyph=None, own_rows=None, halo=0, **ch):
         run.close()
 
 
+@pytest.mark.parametrize("mode", ["two_level", "bands"])
 @pytest.mark.parametrize("rname", ["Sum", "Count", "Average", "Max", "Min"])
-def test_point_bands_match_oracle(A, few_bins, rname):
+def test_point_large_grid_paths_match_oracle(A, few_bins, monkeypatch, rname, mode):
+    monkeypatch.setenv("PCR_HIP_DEBUG_TWO_LEVEL", "1" if mode == "two_level" else "0")
     # 300 x 700 cells = 3 x 8 tiles of 128 x 96 (Sum+Count) -> at most 2 tile rows per band
     og = O.make_grid((0.0, 0.0, 300.0, 700.0), tile=(64, 64))
     rng = np.random.default_rng(11)
@@ -97,8 +100,10 @@ def test_glyph_bands_match_oracle(A, few_bins, kind):
         np.testing.assert_array_equal(gotc, O.run(og, RT["Count"], x, y, v, glyph=ogl, **ch))
 
 
-def test_point_bands_inside_a_row_block_shard(A, few_bins):
-    """Bands and the owned-row window compose: a shard owning rows [200, 520) of 700."""
+@pytest.mark.parametrize("mode", ["two_level", "bands"])
+def test_point_large_grid_paths_inside_a_row_block_shard(A, few_bins, monkeypatch, mode):
+    """Both compose with the owned-row window: a shard owning rows [200, 520) of 700."""
+    monkeypatch.setenv("PCR_HIP_DEBUG_TWO_LEVEL", "1" if mode == "two_level" else "0")
     og = O.make_grid((0.0, 0.0, 300.0, 700.0))
     rng = np.random.default_rng(13)
     n = 100_000
@@ -109,3 +114,22 @@ def test_point_bands_inside_a_row_block_shard(A, few_bins):
     # untouched-tile NaN semantics are per reference tile (one 4096^2 tile here): compare counts where defined
     np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want))
     assert st.points_valid == int(np.nansum(want))
+
+
+def test_two_level_sort_many_tiles_and_hot_tiles(A, monkeypatch):
+    """No debug limit: a 1200 x 9000 grid has 710 tiles -- fewer than 8064, so lower the limit to 100 and
+    let the two-level sort run with ~27 groups; a clustered cloud puts > 16384 records into single groups and tiles."""
+    monkeypatch.setenv("PCR_HIP_DEBUG_MAX_BINS", "100")
+    og = O.make_grid((0.0, 0.0, 1200.0, 9000.0))
+    rng = np.random.default_rng(14)
+    n = 600_000
+    x = np.concatenate([rng.uniform(0, 1200, n // 2), rng.normal(600.0, 15.0, n // 2)])
+    y = np.concatenate([rng.uniform(0, 9000, n // 2), rng.normal(4500.0, 20.0, n // 2)])
+    v = rng.normal(0.0, 1.0, n).astype(np.float32)
+    for rname in ("Count", "Max"):
+        got, st = run_gpu(A, og, RT[rname], x, y, v)
+        assert st.path == 1 and st.num_bins > 100           # e.g. 10 x 71 tiles of 128 x 128 for one 4-byte plane
+        ref = O.Reduction(og, RT[rname])
+        ref.ingest(x, y, v)
+        assert st.points_valid == ref.points_valid()
+        assert_band_close(got, ref.finalize(), what=f"{rname} bit-exact")
