@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--points", type=int, default=50_000_000, help="points per GPU")
     ap.add_argument("--grid", type=int, default=4096, help="grid width = rows per GPU")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU when not square (C5 shard: --grid 16384 --rows 2048)")
     ap.add_argument("--path", default="auto", choices=["auto", "direct", "binned", "moments"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="points of the CPU baseline sample (0 = skip)")
     ap.add_argument("--host-result", action="store_true", help="finalize into host memory (PCIe-inclusive)")
@@ -155,7 +156,8 @@ def main():
         dist.barrier()
 
     G, n = args.grid, args.points
-    H = G * world                                          # rows: one G-row block per GPU
+    R = args.rows if args.rows > 0 else G                  # rows per GPU
+    H = R * world                                          # one R-row block per GPU
     cfg = pcr.PipelineConfig()
     cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(H))
     cfg.grid.cell_size_x, cfg.grid.cell_size_y = 1.0, -1.0
@@ -170,8 +172,8 @@ def main():
     cfg.gpu_pool_size_bytes = 16 * n + (64 << 20)
 
     # this rank's rows [rank*G, (rank+1)*G) <=> world y in (H - (rank+1)*G, H - rank*G)
-    y_hi = float(H - rank * G)
-    y_lo = y_hi - G
+    y_hi = float(H - rank * R)
+    y_lo = y_hi - R
     x, y, v, ch = make_points(args.workload, n, G, y_lo, y_hi, seed=42 + rank)
     cloud = make_cloud(x, y, v, ch)
     if not args.host_cloud:
@@ -226,7 +228,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n,
-                       "grid": f"{G}x{H}", "rows_per_gpu": G, "glyph": glyph,
+                       "grid": f"{G}x{H}", "rows_per_gpu": R, "glyph": glyph,
                        "reductions": [str(r.type).split(".")[-1] for r in cfg.reductions],
                        "scatter_path": info["path"], "lds_tile": list(info["lds_tile"]),
                        "num_bins": info["num_bins"],
