@@ -129,6 +129,10 @@ class ShardedPipeline:
         self.width = cfg.grid.width
         self.halo = self.pipe.halo_rows()
         self._views = None
+        # Touched flags are per reference tile.  When every block edge falls on a tile-row boundary no tile is
+        # shared between ranks and the flags are purely local: a Point-glyph run then needs no collective at all.
+        th = cfg.grid.tile_height
+        self.tiles_local = all(b0 % th == 0 or b0 >= cfg.grid.height for b0, _ in self.blocks)
 
     def _plane_tensors(self):
         if self._views is None:
@@ -148,7 +152,9 @@ class ShardedPipeline:
 
     def exchange(self):
         """Halo reduce + touched-tile union.  No-op for a single rank."""
-        if self.world == 1:
+        # tiles_local: glyph footprints are clipped to the reference tile of their centre cell (Q4), so with
+        # tile-aligned blocks nothing ever lands in a neighbour's rows -- no halo to reduce either
+        if self.world == 1 or self.tiles_local:
             return
         planes = self._plane_tensors()
         # Run the collectives ON the engine's stream (wrapped as a torch ExternalStream): RCCL orders
@@ -164,7 +170,8 @@ class ShardedPipeline:
             if self.halo > 0:
                 exchange_halos(planes, self.own, self.pipe.state_row_begin(), self.halo,
                                self.rank, self.world, blocks=self.blocks, group=self.group)
-            allreduce_touched(self._touched, self.group)
+            if not self.tiles_local:
+                allreduce_touched(self._touched, self.group)
         if not ptr:
             torch.cuda.current_stream().synchronize()
 

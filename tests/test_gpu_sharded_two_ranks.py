@@ -23,7 +23,7 @@ def _inputs():
     return x, y, v
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, tile_h):
     import torch                                   # before pcr: one shared HIP runtime
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
@@ -37,7 +37,7 @@ def _worker(rank, world, port, out_dir):
         x, y, v = _inputs()
         cfg = pcr.PipelineConfig()
         cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G_W), float(G_H))
-        cfg.grid.tile_width, cfg.grid.tile_height = 64, 64     # multi-tile: touched flags matter
+        cfg.grid.tile_width, cfg.grid.tile_height = 64, tile_h  # multi-tile: touched flags matter
         cfg.grid.compute_dimensions()
         cfg.exec_mode = pcr.ExecutionMode.GPU
         cnt = pcr.ReductionSpec()
@@ -56,13 +56,14 @@ def _worker(rank, world, port, out_dir):
         sp.ingest(cloud.to_device())
         sp.finalize()
         res = sp.result()
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), own=np.array(sp.own), halo=sp.halo,
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), own=np.array(sp.own), halo=sp.halo, local=sp.tiles_local,
                  **{f"b{i}": np.array(res.band_array(i)) for i in range(3)})
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_pipeline_matches_oracle(tmp_path):
+@pytest.mark.parametrize("tile_h", [64, 60], ids=["blocks-cut-tiles:exchange", "blocks-on-tile-rows:no-collective"])
+def test_two_rank_sharded_pipeline_matches_oracle(tmp_path, tile_h):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pcr_oracle_py as O
@@ -70,14 +71,14 @@ def test_two_rank_sharded_pipeline_matches_oracle(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), tile_h), nprocs=2, join=True)
     x, y, v = _inputs()
-    og = O.make_grid((0, 0, G_W, G_H), tile=(64, 64))
+    og = O.make_grid((0, 0, G_W, G_H), tile=(64, tile_h))
     want = [O.run(og, O.WEIGHTED_AVERAGE, x, y, v, glyph=O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=2.0, max_radius=6.0)),
             O.run(og, O.COUNT, x, y, v), O.run(og, O.MAX, x, y, v)]
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
     assert parts[0]["own"].tolist() == [0, 60] and parts[1]["own"].tolist() == [60, 120]
-    assert int(parts[0]["halo"]) == 6
+    assert int(parts[0]["halo"]) == 6 and bool(parts[0]["local"]) == (tile_h == 60)
     for b, (rt, at) in enumerate([(1e-4, 1e-6), (0, 0), (0, 0)]):
         got = np.vstack([parts[0][f"b{b}"], parts[1][f"b{b}"]])
         w = want[b]
