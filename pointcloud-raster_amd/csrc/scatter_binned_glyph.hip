@@ -27,6 +27,7 @@ struct GlyphTile {
     int apron;          // LDS apron, cells
     int lw, lh;         // LDS window = interior + 2 * apron
     int need;           // apron the glyph spec can need (>= apron when the LDS could not afford it)
+    int fixed_r;        // Gaussian: the radius every point has (default sigma, no rotation, r <= 5), else 0
 };
 
 // ---- sinks ---------------------------------------------------------------------------------------
@@ -75,7 +76,7 @@ struct LineLdsSink {
 };
 
 // ---- Gaussian tiles ---------------------------------------------------------------------------------
-template <unsigned MASK>
+template <unsigned MASK, int FR>
 __global__ void __launch_bounds__(kThreads)
 k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __restrict__ records,
              const BinItem* __restrict__ items, const unsigned* __restrict__ n_items,
@@ -107,6 +108,10 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
             PointGeom pg = point_geom(g, x[i], y[i]);
             valid = pg.valid;                     // always true for a binned point; keeps q sane
             if (valid) q = gauss_params(g, gl, pg, v[i], load_chan(gl, i));
+        }
+        if (FR > 0) {                      // every point has radius FR: separable, fully unrolled
+            if (valid) gauss_splat_fixed<FR>(q, sink);
+            continue;
         }
         // small footprints (<= 11 x 11): one lane per point; larger ones: the whole wave per point
         const bool big = valid && q.r > 5;
@@ -220,6 +225,14 @@ bool glyph_tile(const pcr_hip_engine* e, const GlyphDev& gl, unsigned mask, Glyp
     if (bands_for(S) > kMaxBands) return false;
     GlyphTile t;
     t.need = need;
+    t.fixed_r = 0;
+    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN && !gl.sigma_x && !gl.sigma_y && !gl.rotation && gl.def_rotation == 0.0f) {
+        // the r of gauss_params (glyph_device.hpp) for the default sigmas
+        const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
+        const float R = std::fmin(3.0f * std::fmax(sx, sy), gl.max_radius);
+        const int r = std::min((int)std::ceil(R), 1 << 20);
+        if (R == R && r >= 1 && r <= 5) t.fixed_r = r;
+    }
     t.apron = std::max(0, std::min(need, (side - S) / 2));
     t.lw = S + 2 * t.apron;
     t.lh = S + 2 * t.apron;
@@ -304,11 +317,19 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
         // the tile kernels re-derive every point's geometry from the engine's grid: the band only selected them
         if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
             ScopedKernelTimer tm(e, "k_tile_gauss");
-            switch (mask) {
-                case 1: launch_gauss(&k_tile_gauss<1>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
-                case 2: launch_gauss(&k_tile_gauss<2>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
-                default: launch_gauss(&k_tile_gauss<3>, e, e->gd, gl, t, pl, bb, lds, x, y, v); break;
+#define PCR_GAUSS(M, FR) launch_gauss(&k_tile_gauss<M, FR>, e, e->gd, gl, t, pl, bb, lds, x, y, v)
+#define PCR_GAUSS_R(M)                                                                          \
+            switch (t.fixed_r) {                                                                \
+                case 1: PCR_GAUSS(M, 1); break;                                                 \
+                case 2: PCR_GAUSS(M, 2); break;                                                 \
+                case 3: PCR_GAUSS(M, 3); break;                                                 \
+                case 4: PCR_GAUSS(M, 4); break;                                                 \
+                case 5: PCR_GAUSS(M, 5); break;                                                 \
+                default: PCR_GAUSS(M, 0); break;                                                \
             }
+            if (mask == 1) { PCR_GAUSS_R(1) } else if (mask == 2) { PCR_GAUSS_R(2) } else { PCR_GAUSS_R(3) }
+#undef PCR_GAUSS_R
+#undef PCR_GAUSS
         } else {
             ScopedKernelTimer tm(e, "k_tile_line");
             switch (mask) {
