@@ -68,7 +68,7 @@ void bind_io(py::module_& m) {
     py::class_<PointCloudReader>(m, "PointCloudReader")
         .def_static("open", [](const std::string& path, PointCloudFormat format) {
             auto r = PointCloudReader::open(path, format);
-            if (!r) throw std::runtime_error("PointCloudReader.open: failed to open " + path);
+            if (!r) throw std::runtime_error("Failed to open point cloud: " + path);
             return r;
         }, py::arg("path"), py::arg("format") = PointCloudFormat::Auto)
         .def("info", &PointCloudReader::info, py::return_value_policy::reference_internal)
@@ -122,7 +122,7 @@ void bind_io(py::module_& m) {
 
     m.def("read_point_cloud", [](const std::string& path, PointCloudFormat format, MemoryLocation location) {
         auto c = read_point_cloud(path, format, location);
-        if (!c) throw std::runtime_error("read_point_cloud: failed to read " + path);
+        if (!c) throw std::runtime_error("Failed to read point cloud: " + path);
         return c;
     }, py::arg("path"), py::arg("format") = PointCloudFormat::Auto, py::arg("location") = MemoryLocation::Host);
     m.def("write_point_cloud", [](const std::string& path, const PointCloud& cloud, PointCloudFormat format) {

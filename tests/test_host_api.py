@@ -182,5 +182,5 @@ def test_io_names_exist():
     for name in ("write_geotiff", "read_geotiff_info", "read_point_cloud", "write_point_cloud",
                  "read_point_cloud_info", "PointCloudReader", "GeoTiffOptions", "PointCloudInfo"):
         assert hasattr(pcr, name)
-    with pytest.raises(RuntimeError, match="failed to read"):
+    with pytest.raises(RuntimeError, match="Failed to read point cloud"):
         pcr.read_point_cloud("/tmp/nope.pcrp")
