@@ -256,7 +256,7 @@ def main():
             out["kernels_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(kernels.items())}
         sample = args.cpu_sample
         if sample < 0:
-            sample = {"point": 20_000_000, "gauss": 0, "line": 4_000_000}[glyph]
+            sample = {"point": 50_000_000, "gauss": 0, "line": 8_000_000}[glyph]          # ~10 s of single-thread CPU work
             if glyph == "gauss":
                 sigma = WORKLOADS[args.workload][2]
                 sample = int(2e9 / (2 * min(3 * sigma, 64) + 1) ** 2 / 4)     # ~10-20 s of cell updates
