@@ -81,7 +81,8 @@ struct BinBuffers {                     // device pointers into the engine's scr
     const unsigned* n_items;
     int max_items;
 };
-constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 12 B per bin <= 160 KB
+constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 8 B per bin; beyond this the runs a
+                                        // block writes per bin are single records anyway (two-level sort / row bands)
 constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
 constexpr int kMaxTiles = 1 << (32 - kLcellBits);   // routing key = tile << 15 | local cell
 constexpr int kMaxSubBins = 2048;       // tiles per first-level group (second-level scatter: 128 KB staging + 12 B per tile)

@@ -18,6 +18,8 @@
 // (src/engine/tile_router_kernels.cu:63-293, src/engine/accumulator_kernels.cu:31-133).
 #include "engine.hpp"
 
+#include <cstdlib>
+
 using namespace pcrhip;
 
 namespace {
@@ -164,11 +166,11 @@ __global__ void __launch_bounds__(kThreads)
 k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, const float* __restrict__ v,
               uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
     extern __shared__ unsigned char lds_raw[];
-    // layout: stage[chunk] (8 B each) | hist[nbins] | loff[nbins] | gbase[nbins]
+    // layout: stage[chunk] (8 B each) | hist[nbins] | loff[nbins]; after the scan hist[bin] is reused for
+    // (global start of the block's run) - loff[bin], so that a staged record j goes to hist[bin] + j
     uint2* stage = reinterpret_cast<uint2*>(lds_raw);
     unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)b.chunk * sizeof(uint2));
     unsigned* loff = hist + b.nbins;
-    unsigned* gbase = loff + b.nbins;
     __shared__ unsigned wave_tot[kThreads / 64];
 
     for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
@@ -233,7 +235,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     for (int i = lo; i < hi; ++i) {
         unsigned c = hist[i];
         loff[i] = run;
-        if (c) gbase[i] = atomicAdd(&cursor[i], c);
+        if (c) hist[i] = atomicAdd(&cursor[i], c) - run;
         run += c;
     }
     unsigned total = 0;
@@ -254,7 +256,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     for (unsigned j = threadIdx.x; j < total; j += kThreads) {
         uint2 rec = stage[j];
         unsigned bin = rec.x >> gshift;
-        unsigned dst = gbase[bin] + (j - loff[bin]);
+        unsigned dst = hist[bin] + j;
         records[dst] = make_uint2(b.sup_shift ? rec.x : rec.x & kLcellMask, rec.y);   // first of two levels: keep the tile
     }
 }
@@ -610,7 +612,7 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     } else {
         ScopedKernelTimer t(e, "k_bin_scatter");
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
-        const size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 3;
+        const size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
         const bool index_records = kind == RecordKind::Index;
         const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;   // d_keys is 256-B aligned
         const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
@@ -695,7 +697,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     }
     {
         ScopedKernelTimer t(e, "k_bin_scatter");
-        const size_t lds = (size_t)l1.chunk * sizeof(uint2) + (size_t)l1.nbins * 4 * 3;
+        const size_t lds = (size_t)l1.chunk * sizeof(uint2) + (size_t)l1.nbins * 4 * 2;
         const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
         const int full_blocks = aligned ? (int)(n / l1.chunk) : 0;
         auto launch = [&](auto kernel, int nblocks, int first) {
