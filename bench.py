@@ -240,7 +240,13 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k][1])
             launches, ms = kernels[dom]
             avg_ms = ms / launches
-            achieved = bpp * n / (avg_ms * 1e-3) / 1e9
+            # points one launch of that kernel processes: all of the ingest, except that the binning scatter is two
+            # launches (whole chunks under "k_bin_scatter", the ragged last chunk under "k_bin_scatter_tail")
+            n_launch = n
+            if dom == "k_bin_scatter":
+                chunk = 16384 if info["num_bins"] <= 2048 else 8192
+                n_launch = (n // chunk) * chunk
+            achieved = bpp * n_launch / (avg_ms * 1e-3) / 1e9
             traffic = None        # HBM bytes per launch of the dominant kernel, from committed rocprofv3 PMC runs
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -252,7 +258,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                                "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
-                               "algorithmic_bytes_per_launch": bpp * n}
+                               "algorithmic_bytes_per_launch": bpp * n_launch}
             out["kernels_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(kernels.items())}
         sample = args.cpu_sample
         if sample < 0:

@@ -610,31 +610,32 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         out->records = nullptr;
         out->grecords = d_rec;
     } else {
-        ScopedKernelTimer t(e, "k_bin_scatter");
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
         const size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
         const bool index_records = kind == RecordKind::Index;
         const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;   // d_keys is 256-B aligned
         const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
-        auto launch = [&](auto kernel, int nblocks, int first) {
+        // two launches, timed under their own names: full chunks (16-byte loads), then the ragged last chunk
+        auto launch = [&](const char* name, auto kernel, int nblocks, int first) {
             if (nblocks <= 0) return;
+            ScopedKernelTimer t(e, name);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, b, first, d_keys, v, n,
                                d_cursor, d_rec);
         };
         if (b.chunk == 16384 && !index_records) {
-            launch(&k_bin_scatter<16, true, false>, full_blocks, 0);
-            launch(&k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
+            launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
         } else if (b.chunk == 16384) {
-            launch(&k_bin_scatter<16, true, true>, full_blocks, 0);
-            launch(&k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
+            launch("k_bin_scatter", &k_bin_scatter<16, true, true>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
         } else if (!index_records) {
-            launch(&k_bin_scatter<8, true, false>, full_blocks, 0);
-            launch(&k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
+            launch("k_bin_scatter", &k_bin_scatter<8, true, false>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
         } else {
-            launch(&k_bin_scatter<8, true, true>, full_blocks, 0);
-            launch(&k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
+            launch("k_bin_scatter", &k_bin_scatter<8, true, true>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
         }
         out->records = d_rec;
         out->grecords = nullptr;
@@ -696,21 +697,21 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
                            U(o_cursor1), d_items1, U(o_nitems1));
     }
     {
-        ScopedKernelTimer t(e, "k_bin_scatter");
         const size_t lds = (size_t)l1.chunk * sizeof(uint2) + (size_t)l1.nbins * 4 * 2;
         const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
         const int full_blocks = aligned ? (int)(n / l1.chunk) : 0;
-        auto launch = [&](auto kernel, int nblocks, int first) {
+        auto launch = [&](const char* name, auto kernel, int nblocks, int first) {
             if (nblocks <= 0) return;
+            ScopedKernelTimer t(e, name);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, l1, first, U(o_keys), v, n, U(o_cursor1), d_rec1);
         };
         if (l1.chunk == 16384) {
-            launch(&k_bin_scatter<16, true, false>, full_blocks, 0);
-            launch(&k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
+            launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
         } else {
-            launch(&k_bin_scatter<8, true, false>, full_blocks, 0);
-            launch(&k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
+            launch("k_bin_scatter", &k_bin_scatter<8, true, false>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
         }
     }
     const int tps = 1 << tiles.sup_shift;
