@@ -41,3 +41,30 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"dimensions must be positive" in L.pcr_hip_last_error()
     n = C.c_int(-1)
     assert L.pcr_hip_device_count(C.byref(n)) == 0 and n.value >= 0
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/pcr_hip.h must be consumable by a C99 compiler (cgo / JNI / ctypes all bind C), and a C program
+    must link against libpcr_hip.so with nothing but the header."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "pointcloud-raster_amd", "lib")
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "pcr_hip.h"\n'
+                   'int main(void) {\n'
+                   '    pcr_hip_engine* e = 0;\n'
+                   '    int rc;\n'
+                   '    printf("abi %d\\n", pcr_hip_abi_version());\n'
+                   '    rc = pcr_hip_engine_create(&e, 0, 0, 0);      /* null grid: rejected before any HIP call */\n'
+                   '    printf("rc %d msg %s\\n", rc, pcr_hip_last_error());\n'
+                   '    return rc == PCR_HIP_INVALID_ARGUMENT ? 0 : 1;\n'
+                   '}\n')
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc not found"
+    exe = tmp_path / "abi"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe), "-L", lib_dir, "-lpcr_hip", f"-Wl,-rpath,{lib_dir}"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi 1" in out.stdout
