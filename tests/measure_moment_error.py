@@ -1,8 +1,9 @@
 """Measured error of the moment + convolution path against the CPU oracle accumulated in double
-(the number DESIGN.md section 3 quotes).  Run on the GPU box: python tools/moment_error.py"""
+(the number DESIGN.md section 3 quotes).  Lives under tests/ because it uses the oracle (test infrastructure).
+Run on the GPU box: python tests/measure_moment_error.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # conftest helpers
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import pcr_oracle_py as O
