@@ -29,6 +29,13 @@ struct pcr_hip_engine {
     std::vector<Pending> pending;
     std::map<std::string, std::pair<uint32_t, double>> kernel_ms;
 
+    // moment path: tap tables of the last glyph spec (host copy; re-uploaded per scatter, rebuilt only on change)
+    struct TapCache {
+        int K = -1, r = -1;
+        float sx = 0.f, sy = 0.f;
+        std::vector<float> taps;               // x taps then y taps
+    } tap_cache;
+
     // scratch of the binned / moment paths: borrowed per scatter from the device-wide arena (engine.hip)
     char* d_scratch = nullptr;
     size_t scratch_cap = 0;

@@ -4,11 +4,13 @@
 // sub-cell offset s (s' = s - 1/2 in [-1/2, 1/2)) can be expanded exactly enough:
 //
 //   exp(-(d - s)^2 / 2 sigma^2) = exp(-u^2/2 sigma^2) * exp(u s'/sigma^2) * exp(-s'^2/2 sigma^2),   u = d - 1/2
-//                               = sum_k A_k(d) m_k(s'),   A_k(d) = exp(-u^2/2 sigma^2) (u/sigma^2)^k / k!,
-//                                                         m_k(s') = s'^k exp(-s'^2/2 sigma^2)
+//                               = sum_k A_k(d) m_k(s'),   A_k(d) = exp(-u^2/2 sigma^2) c_k(u/sigma^2),
+//                                                         m_k(s') = T_k(2 s') exp(-s'^2/2 sigma^2)
 //
-// |u s'/sigma^2| <= (r + 1/2)/(2 sigma^2) is small for large sigma, so a total order K of 4 (sigma=16)
-// to 7 (sigma=4) reproduces every weight to <= 1e-5 relative (bound in make_plan; measured in tests).  Then
+// where c_k(z) are the Chebyshev coefficients of s' -> exp(z s') on [-1/2, 1/2] (c_k ~ 2 (z/4)^k / k!: they
+// fall 2^(k-1) times faster than the Taylor terms (z/2)^k / k!, and |T_k| <= 1 makes the tail bound rigorous).
+// |z| <= (r + 1/2)/sigma^2 is small for sigma >= 2 cells, so a total order K of 4 (sigma=16) to 9 (sigma=2)
+// reproduces every weight to <= 1e-5 relative (bound in make_plan; measured ~1e-6 in tests).  Then
 //
 //   splat = sum_{k+l<=K} (A_k (x) B_l) * M_kl ,   M_kl[cell] = sum_{points centred in cell} v m_k(s'x) n_l(s'y)
 //
@@ -324,10 +326,17 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
             auto fold = [&](const uint4& rc) {
                 const float val = __uint_as_float(rc.y), sx = __uint_as_float(rc.z), sy = __uint_as_float(rc.w);
                 float mx[K + 1], ny[K + 1];
+                // m_k = T_k(2 s') * envelope: T_0 = 1, T_1 = x, T_(k+1) = 2 x T_k - T_(k-1), x = 2 s' in [-1, 1)
+                const float x2 = 2.0f * sx, y2 = 2.0f * sy;
                 mx[0] = expf(-(sx * sx) * inv2sx2);
                 ny[0] = expf(-(sy * sy) * inv2sy2);
+                mx[1] = mx[0] * x2;
+                ny[1] = ny[0] * y2;
 #pragma unroll
-                for (int k = 1; k <= K; ++k) { mx[k] = mx[k - 1] * sx; ny[k] = ny[k - 1] * sy; }
+                for (int k = 2; k <= K; ++k) {
+                    mx[k] = 2.0f * x2 * mx[k - 1] - mx[k - 2];
+                    ny[k] = 2.0f * y2 * ny[k - 1] - ny[k - 2];
+                }
                 int p = 0;
 #pragma unroll
                 for (int k = 0; k <= K; ++k) {
@@ -693,6 +702,29 @@ k_gauss_list(GridDev g, GlyphDev gl, PlanesDev pl, const unsigned* __restrict__ 
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
+// Chebyshev coefficients c_0..c_kmax of s' -> exp(z s') on [-1/2, 1/2] (= x -> exp(z x / 2) on [-1, 1]) by
+// Gauss-Chebyshev quadrature on 64 nodes (exact to rounding for this entire function).
+void cheb_coeffs(double z, int kmax, double* c) {
+    constexpr int N = 64, kTab = 41;
+    static double node[N], cs[kTab][N];
+    static const bool ready = [] {
+        const double pi = 3.14159265358979323846;
+        for (int j = 0; j < N; ++j) {
+            node[j] = std::cos(pi * (j + 0.5) / N);
+            for (int k = 0; k < kTab; ++k) cs[k][j] = std::cos(pi * k * (j + 0.5) / N);
+        }
+        return true;
+    }();
+    (void)ready;
+    double f[N];
+    for (int j = 0; j < N; ++j) f[j] = std::exp(0.5 * z * node[j]);
+    for (int k = 0; k <= kmax && k < kTab; ++k) {
+        double a = 0.0;
+        for (int j = 0; j < N; ++j) a += f[j] * cs[k][j];
+        c[k] = (k == 0 ? 1.0 : 2.0) * a / N;
+    }
+}
+
 // host: plan from the glyph spec; false when the expansion does not apply
 bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     if (gl.type != PCR_HIP_GLYPH_GAUSSIAN || gl.sigma_x || gl.sigma_y || gl.rotation) return false;
@@ -705,17 +737,24 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     // the reference drops weights < 1e-6 (glyph_kernels.cu:166): must never trigger inside the window
     const double qmax = 0.5 * ((r + 1.0) * (r + 1.0) / sx2 + (r + 1.0) * (r + 1.0) / sy2);
     if (qmax > 13.5) return false;
-    // Total order K of the expansion of exp(a + b), |a| + |b| <= t (t = |u s'/sigma^2| summed over both axes):
-    // relative error of a weight <= e^t * sum_{n > K} t^n / n! <= e^t * t^(K+1)/(K+1)! / (1 - t/(K+2)).
-    // The bound is met only on the rim of the footprint (where the weight itself is ~1 % of the peak); K is
-    // the smallest order whose bound is <= 1e-5, a tenth of the 1e-4 tolerance every Gaussian path is tested to.
-    const double t = (r + 0.5) * 0.5 / sx2 + (r + 0.5) * 0.5 / sy2;
-    int K = 0;
-    double term = t;                                                   // t^(K+1)/(K+1)!
-    auto bound = [&]() { return std::exp(t) * term / (1.0 - t / (K + 2)); };
-    while ((t >= K + 2 || bound() > 1e-5) && K < 32) { ++K; term *= t / (K + 1); }
-    if (K > kMaxK) return false;
-    K = K <= 4 ? 4 : K <= 5 ? 5 : K <= 7 ? 7 : 9;                      // instantiated orders
+    // Total order K: the dropped terms are sum_{k+l>K} c_k(zx) T_k c_l(zy) T_l, |T| <= 1, so relative to the true
+    // factor exp(zx s'x + zy s'y) >= exp(-(zx+zy)/2) the error of a weight is <= e^((zx+zy)/2) sum_{k+l>K} |c_k||c_l|,
+    // largest at the rim of the footprint (zx = (r+1/2)/sx^2, where the weight itself is ~1 % of the peak).  K is the
+    // smallest instantiated order whose bound is <= 1e-5, a tenth of the 1e-4 tolerance every Gaussian path is tested to.
+    const double zx = (r + 0.5) / sx2, zy = (r + 0.5) / sy2;
+    constexpr int kTail = 40;
+    double cx[kTail + 1], cy[kTail + 1];
+    cheb_coeffs(zx, kTail, cx);
+    cheb_coeffs(zy, kTail, cy);
+    int K = -1;
+    for (int cand : {4, 5, 6, 7, 9}) {
+        double tail = 0.0;
+        for (int k = 0; k <= kTail; ++k)
+            for (int l = 0; l <= kTail; ++l)
+                if (k + l > cand) tail += std::fabs(cx[k]) * std::fabs(cy[l]);
+        if (std::exp(0.5 * (zx + zy)) * tail <= 1e-5) { K = cand; break; }
+    }
+    if (K < 0) return false;
     MomPlan p;
     p.K = K;
     p.P = (K + 1) * (K + 2) / 2;
@@ -739,13 +778,12 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
 void fill_taps(std::vector<float>& t, int K, int r, double s2) {
     const int tap_w = 2 * r + 1 + 2 * kPad;
     t.assign((size_t)(K + 1) * tap_w, 0.0f);
-    for (int k = 0; k <= K; ++k) {
-        double fact = 1.0;
-        for (int i = 2; i <= k; ++i) fact *= i;
-        for (int d = -r; d <= r; ++d) {
-            double u = d - 0.5;
-            t[(size_t)k * tap_w + kPad + d + r] = (float)(std::exp(-u * u / (2.0 * s2)) * std::pow(u / s2, k) / fact);
-        }
+    double c[kMaxK + 1];
+    for (int d = -r; d <= r; ++d) {
+        const double u = d - 0.5;
+        cheb_coeffs(u / s2, K, c);
+        const double g = std::exp(-u * u / (2.0 * s2));
+        for (int k = 0; k <= K; ++k) t[(size_t)k * tap_w + kPad + d + r] = (float)(g * c[k]);
     }
 }
 
@@ -764,6 +802,7 @@ void dispatch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, con
                       float* mom_v, float* mom_w, int64_t stride) {
     if (p.K == 4) launch_moments<4, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
     else if (p.K == 5) launch_moments<5, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 6) launch_moments<6, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
     else if (p.K == 7) launch_moments<7, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
     else launch_moments<9, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
 }
@@ -827,14 +866,21 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
 
     // tap tables: x taps then y taps
     const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
-    std::vector<float> tx, ty;
-    fill_taps(tx, p.K, p.r, (double)sx * sx);
-    fill_taps(ty, p.K, p.r, (double)sy * sy);
-    PCR_HIP_TRY(hipMemcpyAsync(d_taps, tx.data(), tx.size() * 4, hipMemcpyHostToDevice, e->stream));
-    PCR_HIP_TRY(hipMemcpyAsync(d_taps + tx.size(), ty.data(), ty.size() * 4, hipMemcpyHostToDevice, e->stream));
-    PCR_HIP_TRY(hipStreamSynchronize(e->stream));      // tx, ty are about to go out of scope
+    auto& tc = e->tap_cache;
+    if (tc.K != p.K || tc.r != p.r || tc.sx != sx || tc.sy != sy) {
+        // the previous upload may still be in flight from the old vector
+        PCR_HIP_TRY(hipStreamSynchronize(e->stream));
+        std::vector<float> tx, ty;
+        fill_taps(tx, p.K, p.r, (double)sx * sx);
+        fill_taps(ty, p.K, p.r, (double)sy * sy);
+        tc.taps = tx;
+        tc.taps.insert(tc.taps.end(), ty.begin(), ty.end());
+        tc.K = p.K; tc.r = p.r; tc.sx = sx; tc.sy = sy;
+    }
+    // the host copy lives in the engine: no synchronisation needed after the upload
+    PCR_HIP_TRY(hipMemcpyAsync(d_taps, tc.taps.data(), tc.taps.size() * 4, hipMemcpyHostToDevice, e->stream));
     const float* taps_x = d_taps;
-    const float* taps_y = d_taps + tx.size();
+    const float* taps_y = d_taps + tc.taps.size() / 2;
 
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));

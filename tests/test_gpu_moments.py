@@ -50,6 +50,8 @@ CASES = [
     dict(name="s8_tiles300", G=(700, 100), sigma=(8.0, 8.0), maxr=24.0, n=6000, tile=(300, 48)),        # ragged reference tiles
     dict(name="s4_r6", G=(128, 96), sigma=(4.0, 4.0), maxr=6.0, n=4000, tile=(4096, 4096)),             # smallest window the path takes
     dict(name="s6_manytiles", G=(4200, 6100), sigma=(6.0, 6.0), maxr=18.0, n=20000, tile=(4096, 4096)),   # 33 x 85 = 2805 tiles: 4096-point scatter chunks
+    dict(name="s2_r6", G=(160, 128), sigma=(2.0, 2.0), maxr=8.0, n=6000, tile=(4096, 4096)),              # smallest sigma: order 9
+    dict(name="s3_r9_tiles", G=(200, 150), sigma=(3.0, 3.0), maxr=12.0, n=6000, tile=(64, 64)),
     dict(name="s5_halfcell", G=(256, 128), sigma=(3.0, 3.0), maxr=32.0, n=6000, tile=(4096, 4096), cell=(0.5, -0.5)),
 ]
 
