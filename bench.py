@@ -36,6 +36,7 @@ WORKLOADS = {
     "point_avg": ("Point, Average", "point", ("Average",), 20),
     "C4": ("clustered (10k hotspots), Point, Max+Min", "point", ("Max", "Min"), 20),
     "gauss1": ("Gaussian sigma=1 r<=4, WeightedAverage", "gauss", 1.0, 20),
+    "gauss1.8": ("Gaussian sigma=1.8 r<=6, WeightedAverage", "gauss", 1.8, 20),
     "gauss2": ("Gaussian sigma=2 r<=6, WeightedAverage", "gauss", 2.0, 20),
     "gauss4": ("Gaussian sigma=4 r<=12 (C3), WeightedAverage", "gauss", 4.0, 20),
     "gauss16": ("Gaussian sigma=16 r<=48, WeightedAverage", "gauss", 16.0, 20),

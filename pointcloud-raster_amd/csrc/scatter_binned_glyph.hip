@@ -27,7 +27,7 @@ struct GlyphTile {
     int apron;          // LDS apron, cells
     int lw, lh;         // LDS window = interior + 2 * apron
     int need;           // apron the glyph spec can need (>= apron when the LDS could not afford it)
-    int fixed_r;        // Gaussian: the radius every point has (default sigma, no rotation, r <= 5), else 0
+    int fixed_r;        // Gaussian: the radius every point has (default sigma, no rotation, r <= 7), else 0
 };
 
 // ---- sinks ---------------------------------------------------------------------------------------
@@ -231,7 +231,7 @@ bool glyph_tile(const pcr_hip_engine* e, const GlyphDev& gl, unsigned mask, Glyp
         const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
         const float R = std::fmin(3.0f * std::fmax(sx, sy), gl.max_radius);
         const int r = std::min((int)std::ceil(R), 1 << 20);
-        if (R == R && r >= 1 && r <= 5) t.fixed_r = r;
+        if (R == R && r >= 1 && r <= 7) t.fixed_r = r;      // r = 6, 7: sigmas too small for the moment path's cut-off condition
     }
     t.apron = std::max(0, std::min(need, (side - S) / 2));
     t.lw = S + 2 * t.apron;
@@ -325,6 +325,8 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
                 case 3: PCR_GAUSS(M, 3); break;                                                 \
                 case 4: PCR_GAUSS(M, 4); break;                                                 \
                 case 5: PCR_GAUSS(M, 5); break;                                                 \
+                case 6: PCR_GAUSS(M, 6); break;                                                 \
+                case 7: PCR_GAUSS(M, 7); break;                                                 \
                 default: PCR_GAUSS(M, 0); break;                                                \
             }
             if (mask == 1) { PCR_GAUSS_R(1) } else if (mask == 2) { PCR_GAUSS_R(2) } else { PCR_GAUSS_R(3) }

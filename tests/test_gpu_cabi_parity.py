@@ -313,3 +313,23 @@ def test_state_merge_and_init_match_oracle(A):
         A.check(L.pcr_hip_state_init(rt, da.ptr, n, None))
         OL.pcro_init_state(rt, want.ctypes.data, n)
         np.testing.assert_array_equal(da.to_numpy(), want)
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_default_sigma_gaussian_every_small_radius(A, r):
+    """Default-sigma, unrotated Gaussians of radius r <= 7 take the separable fixed-radius splat of the LDS tiles
+    (r = 8: the general wave-per-point form); anisotropic sigma, tile clipping and grid edges included."""
+    og = O.make_grid((0.0, 0.0, 150.0, 110.0), tile=(64, 48))
+    rng = np.random.default_rng(100 + r)
+    n = 4000
+    x, y = rng.uniform(-1.0, 151.0, n), rng.uniform(-1.0, 111.0, n)
+    v = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    sx, sy = r / 3.0 - 0.01, r / 3.0 * 0.8
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=sx, sigma_y=sy, max_radius=float(r))
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sx, sigma_y=sy, max_radius=float(r))
+    for rname in ("WeightedAverage", "Count"):
+        got, st = gpu_run(A, og, RT[rname], [dict(x=x, y=y, value=v)], glyph=gl, path=2)
+        assert st.path == 1
+        want = O.run(og, RT[rname], x, y, v, glyph=ogl)
+        exact = O.run(og, RT[rname], x, y, v, glyph=ogl, wide=True).astype(np.float64)
+        assert_glyph_close(got, want, exact, f"r={r}/{rname}", False)
