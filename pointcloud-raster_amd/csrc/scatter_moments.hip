@@ -702,6 +702,19 @@ k_gauss_list(GridDev g, GlyphDev gl, PlanesDev pl, const unsigned* __restrict__ 
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
+// tiles of the window `g` describes
+void plan_bins(MomPlan& p, const GridDev& g) {
+    p.bins.tile_w = kTileW;
+    p.bins.tile_h = kTileH;
+    p.bins.bins_x = (g.W + kTileW - 1) / kTileW;
+    p.bins.bins_y = (g.st_rows + kTileH - 1) / kTileH;
+    p.bins.nbins = p.bins.bins_x * p.bins.bins_y;
+    p.bins.chunk = (p.bins.nbins <= 2560 ? 8 : 4) * kThreads;       // scatter staging: 16 B x chunk + 12 B per bin of LDS
+    p.bins.row0 = 0;
+    p.bins.rows = g.st_rows;
+    p.bins.sup_shift = 0;
+}
+
 // Chebyshev coefficients c_0..c_kmax of s' -> exp(z s') on [-1/2, 1/2] (= x -> exp(z x / 2) on [-1, 1]) by
 // Gauss-Chebyshev quadrature on 64 nodes (exact to rounding for this entire function).
 void cheb_coeffs(double z, int kmax, double* c) {
@@ -761,17 +774,42 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     p.r = r;
     p.inv2sx2 = (float)(1.0 / (2.0 * sx2));
     p.inv2sy2 = (float)(1.0 / (2.0 * sy2));
-    p.bins.tile_w = kTileW;
-    p.bins.tile_h = kTileH;
-    p.bins.bins_x = (g.W + kTileW - 1) / kTileW;
-    p.bins.bins_y = (g.st_rows + kTileH - 1) / kTileH;
-    p.bins.nbins = p.bins.bins_x * p.bins.bins_y;
-    p.bins.chunk = (p.bins.nbins <= 2560 ? 8 : 4) * kThreads;
-    p.bins.row0 = 0;
-    p.bins.rows = g.st_rows;
-    p.bins.sup_shift = 0;
-    if (p.bins.nbins > kMaxBins) return false;                         // scatter staging: 16 B x chunk + 12 B per bin of LDS
+    plan_bins(p, g);
     *out = p;
+    return true;
+}
+
+// A grid whose window has more moment tiles than one binning pass takes is processed in row bands: each band is a
+// complete run of the path on a WINDOW of the state (the band's rows plus r rows on either side, where its points'
+// footprints can land), with the points whose centre row lies in the band.  Moment and U planes only ever cover
+// one window (16384^2 at order 6: 17 GB per band instead of 68 GB), and the windows' outputs add up in the state.
+struct MomBand {
+    int own_r0, own_r1;       // rows (grid coordinates) whose points this band takes
+    int win_r0, win_rows;     // the band's window, in rows of the engine's state window
+};
+
+bool plan_bands(const pcr_hip_engine* e, const MomPlan& p, std::vector<MomBand>* bands) {
+    const GridDev& g = e->gd;
+    const int bins_x = (g.W + kTileW - 1) / kTileW;
+    const int max_tile_rows = e->max_bins / bins_x;
+    const int rows_total = g.st_rows;
+    if ((rows_total + kTileH - 1) / kTileH <= max_tile_rows) {                  // one band: the whole window
+        if (bands) bands->push_back({g.own_r0, g.own_r1, 0, rows_total});
+        return true;
+    }
+    const int band_rows = max_tile_rows * kTileH - 2 * p.r;
+    if (band_rows < kTileH) return false;
+    const int nbands = (rows_total + band_rows - 1) / band_rows;
+    if (nbands > kMaxBands) return false;
+    for (int b0 = 0; b0 < rows_total && bands; b0 += band_rows) {
+        const int b1 = std::min(rows_total, b0 + band_rows);
+        MomBand mb;
+        mb.own_r0 = std::max(g.own_r0, g.st_r0 + b0);
+        mb.own_r1 = std::min(g.own_r1, g.st_r0 + b1);
+        mb.win_r0 = std::max(0, b0 - p.r);
+        mb.win_rows = std::min(rows_total, b1 + p.r) - mb.win_r0;
+        if (mb.own_r0 < mb.own_r1) bands->push_back(mb);
+    }
     return true;
 }
 
@@ -788,23 +826,23 @@ void fill_taps(std::vector<float>& t, int K, int r, double s2) {
 }
 
 template <int K, unsigned MASK>
-void launch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
+void launch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                     float* mom_v, float* mom_w, int64_t stride) {
     const size_t lds = ((size_t)kTileCells * 2 + 1) * sizeof(unsigned) + (size_t)kSortChunk * sizeof(unsigned short) + 16;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_moments<K, MASK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tile_moments<K, MASK>), dim3(p.bins.nbins), dim3(kMomThreads), lds, e->stream, e->gd,
+    hipLaunchKernelGGL((k_tile_moments<K, MASK>), dim3(p.bins.nbins), dim3(kMomThreads), lds, e->stream, gw,
                        p.bins, p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
 }
 
 template <unsigned MASK>
-void dispatch_moments(pcr_hip_engine* e, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
+void dispatch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                       float* mom_v, float* mom_w, int64_t stride) {
-    if (p.K == 4) launch_moments<4, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
-    else if (p.K == 5) launch_moments<5, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
-    else if (p.K == 6) launch_moments<6, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
-    else if (p.K == 7) launch_moments<7, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
-    else launch_moments<9, MASK>(e, p, rec, bin_start, mom_v, mom_w, stride);
+    if (p.K == 4) launch_moments<4, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 5) launch_moments<5, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 6) launch_moments<6, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 7) launch_moments<7, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
+    else launch_moments<9, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
 }
 
 }  // namespace
@@ -814,7 +852,7 @@ namespace pcrhip {
 bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask) {
     if (mask == 0 || (mask & ~3u)) return false;
     MomPlan p;
-    if (!make_plan(e->gd, gl, &p)) return false;
+    if (!make_plan(e->gd, gl, &p) || !plan_bands(e, p, nullptr)) return false;
     if (e->stats.points_in >= (1ull << 32) - (1ull << 20)) return false;
     if (e->forced_path == 3) return true;
     // worth it when painting footprints costs more than the point-count independent convolutions
@@ -830,24 +868,29 @@ bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mas
 int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
                   const double* x, const double* y, const float* v, uint64_t n) {
     MomPlan p;
-    if (!make_plan(e->gd, gl, &p)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path not applicable");
-    const GridDev& g = e->gd;
-    const BinGeom& b = p.bins;
-    const int64_t cells = (int64_t)g.W * g.st_rows;
+    std::vector<MomBand> bands;
+    if (!make_plan(e->gd, gl, &p) || !plan_bands(e, p, &bands))
+        return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path not applicable");
     const int kinds = ((mask & 1) ? 1 : 0) + ((mask & 2) ? 1 : 0);
     const int tap_w = 2 * p.r + 1 + 2 * kPad;
+    int max_rows = 0, max_bins = 0;
+    for (const MomBand& mb : bands) {
+        max_rows = std::max(max_rows, mb.win_rows);
+        max_bins = std::max(max_bins, p.bins.bins_x * ((mb.win_rows + kTileH - 1) / kTileH));
+    }
+    const int64_t max_cells = (int64_t)e->gd.W * max_rows;
 
     size_t off = 0;
-    const size_t o_count = off;  off += align256((size_t)b.nbins * 4);
-    const size_t o_start = off;  off += align256((size_t)(b.nbins + 1) * 4);
-    const size_t o_cursor = off; off += align256((size_t)b.nbins * 4);
+    const size_t o_count = off;  off += align256((size_t)max_bins * 4);
+    const size_t o_start = off;  off += align256((size_t)(max_bins + 1) * 4);
+    const size_t o_cursor = off; off += align256((size_t)max_bins * 4);
     const size_t o_fbc = off;    off += 256;
     const size_t o_taps = off;   off += align256((size_t)2 * (p.K + 1) * tap_w * 4);
     const size_t o_keys = off;   off += align256((size_t)n * 4);
     const size_t o_fbl = off;    off += align256((size_t)n * 4);
     const size_t o_rec = off;    off += align256((size_t)n * 16);
-    const size_t o_mom = off;    off += align256((size_t)kinds * p.P * cells * 4);
-    const size_t o_u = off;      off += align256((size_t)(p.K + 1) * cells * 4);
+    const size_t o_mom = off;    off += align256((size_t)kinds * p.P * max_cells * 4);
+    const size_t o_u = off;      off += align256((size_t)(p.K + 1) * max_cells * 4);
     int rc = ensure_scratch(e, off);
     if (rc) return rc;
     char* s = e->d_scratch;
@@ -861,11 +904,9 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     uint4* d_rec = reinterpret_cast<uint4*>(s + o_rec);
     float* d_mom = reinterpret_cast<float*>(s + o_mom);
     float* d_u = reinterpret_cast<float*>(s + o_u);
-    float* mom_v = (mask & 1) ? d_mom : nullptr;
-    float* mom_w = (mask & 2) ? d_mom + ((mask & 1) ? (int64_t)p.P * cells : 0) : nullptr;
 
     // tap tables: x taps then y taps
-    const float sx = gl.def_sigma_x * (float)g.inv_csx, sy = gl.def_sigma_y * (float)g.inv_csy;
+    const float sx = gl.def_sigma_x * (float)e->gd.inv_csx, sy = gl.def_sigma_y * (float)e->gd.inv_csy;
     auto& tc = e->tap_cache;
     if (tc.K != p.K || tc.r != p.r || tc.sx != sx || tc.sy != sy) {
         // the previous upload may still be in flight from the old vector
@@ -882,46 +923,13 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     const float* taps_x = d_taps;
     const float* taps_y = d_taps + tc.taps.size() / 2;
 
-    PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
-    PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));
-    const int blocks = (int)((n + b.chunk - 1) / b.chunk);
-    {
-        ScopedKernelTimer t(e, "k_mom_count");
-        hipLaunchKernelGGL(k_mom_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream, g, b, x, y, v, n,
-                           d_keys, d_count, d_fbl, d_fbc, e->d_touched, e->d_counters);
-    }
-    {
-        ScopedKernelTimer t(e, "k_mom_scan");
-        hipLaunchKernelGGL(k_mom_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, d_count, d_start, d_cursor);
-    }
-    {
-        ScopedKernelTimer t(e, "k_mom_scatter");
-        const size_t lds = (size_t)b.chunk * 16 + (size_t)b.nbins * 12;
-        auto launch = [&](auto kernel) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds, e->stream, g, b, d_keys, x, y, v, n, d_cursor, d_rec);
-        };
-        if (b.chunk == 8 * kThreads) launch(&k_mom_scatter<8>);
-        else launch(&k_mom_scatter<4>);
-    }
-    {
-        ScopedKernelTimer t(e, "k_tile_moments");
-        if (mask == 1) dispatch_moments<1>(e, p, d_rec, d_start, mom_v, mom_w, cells);
-        else if (mask == 2) dispatch_moments<2>(e, p, d_rec, d_start, mom_v, mom_w, cells);
-        else dispatch_moments<3>(e, p, d_rec, d_start, mom_v, mom_w, cells);
-    }
-    // convolutions, per plane kind
-    const int yblocks = (std::min(g.th, g.H) + 63) / 64;
-    const int tiles_y = g.tiles_y, tiles_x = g.tiles_x;
+    // shapes that do not depend on the band
+    const GridDev& ge = e->gd;
+    const int yblocks = (std::min(ge.th, ge.H) + 63) / 64;
     const size_t col_lds = (size_t)(64 + 2 * p.r + 4) * 64 * sizeof(float);
     const int col_rows_per_wave = (64 + 2 * p.r + 4 + 3) / 4;
-    const dim3 col_grid((g.W + 63) / 64, tiles_y * yblocks, p.K + 1);
-    auto launch_col = [&](auto kernel, const float* src) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
-        hipLaunchKernelGGL(kernel, col_grid, dim3(256), col_lds, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
-    };
     // row pass shape: the strip width (1024 / 256 / 64 columns) that wastes the fewest lanes on this tile width
-    const int eff_tw = std::min(g.tw, g.W);
+    const int eff_tw = std::min(ge.tw, ge.W);
     int lpr_shift = 6;
     double best = -1.0;
     for (int sh : {6, 4, 2}) {
@@ -936,49 +944,106 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     const size_t row_lds = (size_t)4 * rw * rs * sizeof(float);
     const int xunits = (eff_tw + cols - 1) / cols;
     const int npr_need = (spanp + 63) / 64;                             // 64-column loads per row of a strip
-    const dim3 row_grid(tiles_x * xunits, ((g.st_rows + rw - 1) / rw + 3) / 4);
-    auto launch_row = [&](auto kernel, const float* src, float* outp) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
-        hipLaunchKernelGGL(kernel, row_grid, dim3(256), row_lds, e->stream, g, p.K, p.r, xunits, rs, taps_x, src, cells, outp);
-    };
-    for (int kind = 0; kind < 2; ++kind) {
-        const float* mom = kind == 0 ? mom_v : mom_w;
-        float* outp = kind == 0 ? pl.sum : pl.wgt;
-        if (!mom) continue;
+    const int blocks = (int)((n + p.bins.chunk - 1) / p.bins.chunk);
+
+    int total_bins = 0;
+    for (const MomBand& mb : bands) {
+        // the band's window as a grid of its own: every kernel below indexes rows relative to it
+        GridDev g = ge;
+        g.own_r0 = mb.own_r0;
+        g.own_r1 = mb.own_r1;
+        g.st_r0 = ge.st_r0 + mb.win_r0;
+        g.st_rows = mb.win_rows;
+        MomPlan pb = p;
+        plan_bins(pb, g);
+        pb.bins.chunk = p.bins.chunk;                                   // one launch shape for every band
+        if (pb.bins.nbins > 2560 && pb.bins.chunk != 4 * kThreads) return fail(PCR_HIP_CUDA_ERROR, "moment path: band larger than planned");
+        const BinGeom& b = pb.bins;
+        total_bins += b.nbins;
+        const int64_t cells = (int64_t)g.W * g.st_rows;
+        float* mom_v = (mask & 1) ? d_mom : nullptr;
+        float* mom_w = (mask & 2) ? d_mom + ((mask & 1) ? (int64_t)p.P * cells : 0) : nullptr;
+        const int64_t win_off = (int64_t)mb.win_r0 * g.W;             // the window's first row in the state planes
+
+        PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
+        PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));
         {
-            ScopedKernelTimer t(e, "k_conv_col");
-            if (col_rows_per_wave <= 24) launch_col(&k_conv_col<24>, mom);
-            else if (col_rows_per_wave <= 32) launch_col(&k_conv_col<32>, mom);
-            else if (col_rows_per_wave <= 48) launch_col(&k_conv_col<48>, mom);
-            else launch_col(&k_conv_col<0>, mom);
+            ScopedKernelTimer t(e, "k_mom_count");
+            hipLaunchKernelGGL(k_mom_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream, g, b, x, y, v, n,
+                               d_keys, d_count, d_fbl, d_fbc, e->d_touched, e->d_counters);
         }
         {
-            ScopedKernelTimer t(e, "k_conv_row_accum");
-            if (lpr_shift == 6) {
-                if (npr_need <= 20) launch_row(&k_conv_row_accum<6, 20>, d_u, outp);
-                else launch_row(&k_conv_row_accum<6, 0>, d_u, outp);
-            } else if (lpr_shift == 4) {
-                if (npr_need <= 6) launch_row(&k_conv_row_accum<4, 6>, d_u, outp);
-                else launch_row(&k_conv_row_accum<4, 0>, d_u, outp);
-            } else {
-                if (npr_need <= 3) launch_row(&k_conv_row_accum<2, 3>, d_u, outp);
-                else launch_row(&k_conv_row_accum<2, 0>, d_u, outp);
+            ScopedKernelTimer t(e, "k_mom_scan");
+            hipLaunchKernelGGL(k_mom_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, d_count, d_start, d_cursor);
+        }
+        {
+            ScopedKernelTimer t(e, "k_mom_scatter");
+            const size_t lds = (size_t)b.chunk * 16 + (size_t)b.nbins * 12;
+            auto launch = [&](auto kernel) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds, e->stream, g, b, d_keys, x, y, v, n, d_cursor, d_rec);
+            };
+            if (b.chunk == 8 * kThreads) launch(&k_mom_scatter<8>);
+            else launch(&k_mom_scatter<4>);
+        }
+        {
+            ScopedKernelTimer t(e, "k_tile_moments");
+            if (mask == 1) dispatch_moments<1>(e, g, pb, d_rec, d_start, mom_v, mom_w, cells);
+            else if (mask == 2) dispatch_moments<2>(e, g, pb, d_rec, d_start, mom_v, mom_w, cells);
+            else dispatch_moments<3>(e, g, pb, d_rec, d_start, mom_v, mom_w, cells);
+        }
+        // convolutions, per plane kind
+        const dim3 col_grid((g.W + 63) / 64, g.tiles_y * yblocks, p.K + 1);
+        auto launch_col = [&](auto kernel, const float* src) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
+            hipLaunchKernelGGL(kernel, col_grid, dim3(256), col_lds, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
+        };
+        const dim3 row_grid(g.tiles_x * xunits, ((g.st_rows + rw - 1) / rw + 3) / 4);
+        auto launch_row = [&](auto kernel, const float* src, float* outp) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+            hipLaunchKernelGGL(kernel, row_grid, dim3(256), row_lds, e->stream, g, p.K, p.r, xunits, rs, taps_x, src, cells, outp);
+        };
+        for (int kind = 0; kind < 2; ++kind) {
+            const float* mom = kind == 0 ? mom_v : mom_w;
+            float* outp = (kind == 0 ? pl.sum : pl.wgt);
+            if (!mom) continue;
+            outp += win_off;
+            {
+                ScopedKernelTimer t(e, "k_conv_col");
+                if (col_rows_per_wave <= 24) launch_col(&k_conv_col<24>, mom);
+                else if (col_rows_per_wave <= 32) launch_col(&k_conv_col<32>, mom);
+                else if (col_rows_per_wave <= 48) launch_col(&k_conv_col<48>, mom);
+                else launch_col(&k_conv_col<0>, mom);
+            }
+            {
+                ScopedKernelTimer t(e, "k_conv_row_accum");
+                if (lpr_shift == 6) {
+                    if (npr_need <= 20) launch_row(&k_conv_row_accum<6, 20>, d_u, outp);
+                    else launch_row(&k_conv_row_accum<6, 0>, d_u, outp);
+                } else if (lpr_shift == 4) {
+                    if (npr_need <= 6) launch_row(&k_conv_row_accum<4, 6>, d_u, outp);
+                    else launch_row(&k_conv_row_accum<4, 0>, d_u, outp);
+                } else {
+                    if (npr_need <= 3) launch_row(&k_conv_row_accum<2, 3>, d_u, outp);
+                    else launch_row(&k_conv_row_accum<2, 0>, d_u, outp);
+                }
             }
         }
-    }
-    {
-        ScopedKernelTimer t(e, "k_gauss_list");
-        const int fb_blocks = 64;                               // the list is normally empty; grid-strided
-        if (mask == 1) hipLaunchKernelGGL(k_gauss_list<1>, dim3(fb_blocks), dim3(256), 0, e->stream, g, gl, pl, d_fbl, d_fbc, x, y, v);
-        else if (mask == 2) hipLaunchKernelGGL(k_gauss_list<2>, dim3(fb_blocks), dim3(256), 0, e->stream, g, gl, pl, d_fbl, d_fbc, x, y, v);
-        else hipLaunchKernelGGL(k_gauss_list<3>, dim3(fb_blocks), dim3(256), 0, e->stream, g, gl, pl, d_fbl, d_fbc, x, y, v);
+        {
+            // points the expansion cannot represent: painted directly, on the engine's own grid and planes
+            ScopedKernelTimer t(e, "k_gauss_list");
+            const int fb_blocks = 64;                               // the list is normally empty; grid-strided
+            if (mask == 1) hipLaunchKernelGGL(k_gauss_list<1>, dim3(fb_blocks), dim3(256), 0, e->stream, ge, gl, pl, d_fbl, d_fbc, x, y, v);
+            else if (mask == 2) hipLaunchKernelGGL(k_gauss_list<2>, dim3(fb_blocks), dim3(256), 0, e->stream, ge, gl, pl, d_fbl, d_fbc, x, y, v);
+            else hipLaunchKernelGGL(k_gauss_list<3>, dim3(fb_blocks), dim3(256), 0, e->stream, ge, gl, pl, d_fbl, d_fbc, x, y, v);
+        }
     }
     PCR_HIP_TRY(hipGetLastError());
     e->stats.path = 2;
     e->stats.lds_tile_w = kTileW;
     e->stats.lds_tile_h = kTileH;
     e->stats.lds_apron = p.K;           // reported: expansion order
-    e->stats.num_bins = b.nbins;
+    e->stats.num_bins = total_bins;
     return PCR_HIP_OK;
 }
 

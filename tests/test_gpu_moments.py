@@ -155,3 +155,36 @@ def test_moment_path_refuses_what_it_cannot_represent(A):
             run.scatter([5.0], [5.0], [1.0], glyph=dict(type=A.GLYPH_GAUSSIAN, sigma_x=1.0, sigma_y=1.0, max_radius=4.0))
     finally:
         run.close()
+
+
+@pytest.mark.parametrize("rname", ["WeightedAverage", "Count"])
+@pytest.mark.parametrize("tile", [(4096, 4096), (96, 80)], ids=["one-tile", "tiles-cut-bands"])
+def test_moment_path_in_row_bands(A, monkeypatch, rname, tile):
+    """A window with more moment tiles than one binning pass takes is processed band by band (each band: its own
+    moment planes over band rows + r, outputs added into the state).  PCR_HIP_DEBUG_MAX_BINS forces that on a grid
+    the oracle finishes quickly: 200 x 700 cells, 2 x 10 tiles, at most 8 per pass -> 4-row-of-tiles windows."""
+    monkeypatch.setenv("PCR_HIP_DEBUG_MAX_BINS", "8")
+    W, H = 200, 700
+    og = O.make_grid((0.0, 0.0, float(W), float(H)), tile=tile)
+    rng = np.random.default_rng(23)
+    n = 12000
+    x = rng.uniform(-2.0, W + 2.0, n)
+    y = rng.uniform(-2.0, H + 2.0, n)
+    v = rng.normal(10.0, 3.0, n).astype(np.float32)
+    v[7] = np.inf                                                  # one fallback point per band structure
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=7.0, max_radius=24.0)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=8.0, sigma_y=7.0, max_radius=24.0)
+    rt = RT[rname]
+    got, st, run = run_gpu(A, og, rt, x, y, v, gl, path=3)
+    run.close()
+    assert st.path == 2 and st.num_bins > 8 * 2, "the band sweep was not taken"
+    ref = O.Reduction(og, rt, ogl)
+    ref.ingest(x, y, v)
+    assert st.points_valid == ref.points_valid()
+    want = ref.finalize()
+    exact = O.run(og, rt, x, y, v, glyph=ogl, wide=True).astype(np.float64)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    err = np.abs(got[fin].astype(np.float64) - exact[fin])
+    ref_mag = np.maximum(1e-3 * (1.0 if rname == "Count" else 10.0), np.abs(exact[fin]))
+    assert (err <= 1e-4 * ref_mag).all(), f"max rel err {np.max(err / ref_mag):.3e}"
