@@ -112,6 +112,12 @@ enum class RecordKind { Value, Index, Glyph };
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
                uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out);
 
+// Two-level counting sort (groups of 2^shift tiles, then tiles) for windows with more tiles than one pass counts;
+// 8-byte Value or Index records.  two_level_shift: 0 when not applicable (disabled, or more than kMaxTiles tiles).
+int two_level_shift(const pcr_hip_engine* e, int tiles);
+int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* x, const double* y, const float* v,
+                         uint64_t n, bool index_records, unsigned item_records, BinBuffers* out);
+
 // direct path (global atomics), scatter_direct.hip
 int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n);

@@ -659,7 +659,7 @@ int two_level_shift(const pcr_hip_engine* e, int tiles) {
 }
 
 int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* x, const double* y, const float* v,
-                         uint64_t n, unsigned item_records, BinBuffers* out) {
+                         uint64_t n, bool index_records, unsigned item_records, BinBuffers* out) {
     BinGeom l1 = tiles;                                                   // first level: groups of tiles
     l1.nbins = (tiles.nbins + (1 << tiles.sup_shift) - 1) >> tiles.sup_shift;
     l1.chunk = l1.nbins <= 2048 ? 16384 : 8192;
@@ -698,7 +698,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     }
     {
         const size_t lds = (size_t)l1.chunk * sizeof(uint2) + (size_t)l1.nbins * 4 * 2;
-        const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+        const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;
         const int full_blocks = aligned ? (int)(n / l1.chunk) : 0;
         auto launch = [&](const char* name, auto kernel, int nblocks, int first) {
             if (nblocks <= 0) return;
@@ -706,12 +706,18 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, l1, first, U(o_keys), v, n, U(o_cursor1), d_rec1);
         };
-        if (l1.chunk == 16384) {
+        if (l1.chunk == 16384 && !index_records) {
             launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
             launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
-        } else {
+        } else if (l1.chunk == 16384) {
+            launch("k_bin_scatter", &k_bin_scatter<16, true, true>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
+        } else if (!index_records) {
             launch("k_bin_scatter", &k_bin_scatter<8, true, false>, full_blocks, 0);
             launch("k_bin_scatter_tail", &k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
+        } else {
+            launch("k_bin_scatter", &k_bin_scatter<8, true, true>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
         }
     }
     const int tps = 1 << tiles.sup_shift;
@@ -773,7 +779,7 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     if (shift > 0) {                                            // one sweep, two sort levels
         b.sup_shift = shift;
         BinBuffers bb{};
-        int rc = bin_points_two_level(e, b, x, y, v, n, kPointItemRecords, &bb);
+        int rc = bin_points_two_level(e, b, x, y, v, n, false, kPointItemRecords, &bb);
         if (rc) return rc;
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {

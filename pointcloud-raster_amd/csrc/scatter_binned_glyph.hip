@@ -296,6 +296,42 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
     const size_t lds = (size_t)t.lw * t.lh * cell_bytes(gl.type, mask);
     const int S = t.bins.tile_h;
     int total_bins = 0;
+    // Gaussian on a window with more tiles than one pass counts: the 8-byte index records go through the same
+    // two-level sort as the Point glyph (one sweep instead of one per row band)
+    if (gl.type == PCR_HIP_GLYPH_GAUSSIAN && band_rows < e->gd.st_rows) {
+        const int shift = two_level_shift(e, t.bins.nbins);
+        if (shift > 0) {
+            t.bins.sup_shift = shift;
+            BinBuffers bb{};
+            int rc = bin_points_two_level(e, t.bins, x, y, nullptr, n, true, item_points, &bb);
+            if (rc) return rc;
+            {
+                ScopedKernelTimer tm(e, "k_tile_gauss");
+#define PCR_GAUSS(M, FR) launch_gauss(&k_tile_gauss<M, FR>, e, e->gd, gl, t, pl, bb, lds, x, y, v)
+#define PCR_GAUSS_R(M)                                                                          \
+                switch (t.fixed_r) {                                                            \
+                    case 1: PCR_GAUSS(M, 1); break;                                             \
+                    case 2: PCR_GAUSS(M, 2); break;                                             \
+                    case 3: PCR_GAUSS(M, 3); break;                                             \
+                    case 4: PCR_GAUSS(M, 4); break;                                             \
+                    case 5: PCR_GAUSS(M, 5); break;                                             \
+                    case 6: PCR_GAUSS(M, 6); break;                                             \
+                    case 7: PCR_GAUSS(M, 7); break;                                             \
+                    default: PCR_GAUSS(M, 0); break;                                            \
+                }
+                if (mask == 1) { PCR_GAUSS_R(1) } else if (mask == 2) { PCR_GAUSS_R(2) } else { PCR_GAUSS_R(3) }
+#undef PCR_GAUSS_R
+#undef PCR_GAUSS
+            }
+            PCR_HIP_TRY(hipGetLastError());
+            e->stats.path = 1;
+            e->stats.lds_tile_w = t.bins.tile_w;
+            e->stats.lds_tile_h = t.bins.tile_h;
+            e->stats.lds_apron = t.apron;
+            e->stats.num_bins = t.bins.nbins;
+            return PCR_HIP_OK;
+        }
+    }
     // row bands: a band bins the points whose CENTRE row it holds; footprints reach into neighbouring
     // bands through the apron / global-atomic spill exactly as they reach into neighbouring tiles
     for (int row0 = 0; row0 < e->gd.st_rows; row0 += band_rows) {

@@ -68,8 +68,11 @@ def test_point_large_grid_paths_match_oracle(A, few_bins, monkeypatch, rname, mo
         assert (err <= tol).all(), f"max err {err.max()}"
 
 
+@pytest.mark.parametrize("mode", ["two_level", "bands"])
 @pytest.mark.parametrize("kind", ["gauss", "line"])
-def test_glyph_bands_match_oracle(A, few_bins, kind):
+def test_glyph_large_grid_paths_match_oracle(A, few_bins, monkeypatch, kind, mode):
+    # Gaussian index records take the two-level sort; the Line's 32-byte records always sweep bands
+    monkeypatch.setenv("PCR_HIP_DEBUG_TWO_LEVEL", "1" if mode == "two_level" else "0")
     og = O.make_grid((0.0, 0.0, 200.0, 600.0), tile=(4096, 4096))
     rng = np.random.default_rng(12)
     n = 20_000
