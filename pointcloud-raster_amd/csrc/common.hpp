@@ -79,6 +79,18 @@ int validate_grid(const pcr_hip_grid* g);
 
 #if defined(__HIPCC__)
 
+// n / d for 0 <= n, d >= 1 without the ~25-instruction integer division sequence: one float multiply plus a
+// correction step, exact for n < 2^24 and d >= 8 (float holds n exactly and the product is off by less than
+// 2^-3 * n / 2^24 < 1); anything else divides for real.  The per-point routing does four of these (tile and bin
+// of a cell): they were most of k_bin_count's VALU work.
+__device__ __forceinline__ int fast_div(int n, int d) {
+    if (n >= (1 << 24) || d < 8) return n / d;
+    int q = (int)((float)n * __frcp_rn((float)d));
+    int r = n - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+
 // ---- routing: GridConfig::world_to_cell (src/core/grid_config.cpp:24-43) ------
 // Inclusive bounds (BBox::contains, src/core/types.cpp:41-43), floor of a TRUE f64
 // division, clamp.  NaN coordinates fail the bounds test, as on the CPU.
@@ -132,7 +144,7 @@ __device__ __forceinline__ void atomic_min_f32(float* p, float v) {
 
 // Mark the reference tile of (row, col) as having state (pipeline.cpp:688-691, 1220).
 __device__ __forceinline__ void touch_tile(const GridDev& g, uint32_t* touched, int row, int col) {
-    int t = (row / g.th) * g.tiles_x + (col / g.tw);
+    int t = fast_div(row, g.th) * g.tiles_x + fast_div(col, g.tw);
     // agent-scope relaxed load: served by L2, never by a stale L1 line, so the flag is
     // written only until the first store lands.
     if (__hip_atomic_load(touched + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)

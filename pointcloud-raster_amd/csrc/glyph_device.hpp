@@ -27,7 +27,7 @@ __device__ __forceinline__ PointGeom point_geom(const GridDev& g, double wx, dou
     p.valid = p.valid && p.row >= g.own_r0 && p.row < g.own_r1;
     p.fcx = (wx - g.min_x) * g.inv_csx;
     p.fcy = (wy - g.max_y) * g.inv_csy;
-    int tcx = p.valid ? p.col / g.tw : 0, tcy = p.valid ? p.row / g.th : 0;
+    int tcx = p.valid ? fast_div(p.col, g.tw) : 0, tcy = p.valid ? fast_div(p.row, g.th) : 0;
     p.cx0 = tcx * g.tw;
     p.cx1 = min(p.cx0 + g.tw, g.W);
     p.cy0 = max(tcy * g.th, g.st_r0);

@@ -41,7 +41,7 @@ __device__ __forceinline__ Routed route(const GridDev& g, const BinGeom& b, doub
     r.valid = world_to_cell(g, wx, wy, r.col, r.row);
     r.valid = r.valid && r.row >= g.own_r0 && r.row < g.own_r1;
     int sr = r.row - g.st_r0 - b.row0;                 // valid points lie inside the band: sr >= 0
-    int bx = r.col / b.tile_w, by = sr / b.tile_h;
+    int bx = fast_div(r.col, b.tile_w), by = fast_div(sr, b.tile_h);
     r.bin = by * b.bins_x + bx;
     r.lcell = (unsigned)((sr - by * b.tile_h) * b.tile_w + (r.col - bx * b.tile_w));
     return r;

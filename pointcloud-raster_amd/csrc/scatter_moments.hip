@@ -73,7 +73,7 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);
         if (finite_f(val) && icx == pg.col && icy == pg.row) {
             int sr = pg.row - g.st_r0;
-            int bx = pg.col / b.tile_w, by = sr / b.tile_h;
+            int bx = fast_div(pg.col, b.tile_w), by = fast_div(sr, b.tile_h);
             int bin = by * b.bins_x + bx;
             atomicAdd(&lds_hist[bin], 1u);
             return ((unsigned)bin << kLcellBits) | (unsigned)((sr - by * b.tile_h) * b.tile_w + (pg.col - bx * b.tile_w));
