@@ -1,0 +1,126 @@
+"""Randomised differential test of the HOST layer (pcr.Pipeline): several ReductionSpecs of mixed glyphs and value
+channels in one pipeline (accumulation groups, shared passes, fused finalize), an optional FilterSpec, several
+ingests from host / device clouds -- every finalized band against the CPU oracle run for that spec alone on the
+filtered, concatenated points.  Seeds 0..39; a failure names its seed."""
+import numpy as np
+import pytest
+
+import pcr
+import pcr_oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+RT = {"Sum": (pcr.ReductionType.Sum, O.SUM), "Max": (pcr.ReductionType.Max, O.MAX), "Min": (pcr.ReductionType.Min, O.MIN),
+      "Average": (pcr.ReductionType.Average, O.AVERAGE), "WeightedAverage": (pcr.ReductionType.WeightedAverage, O.WEIGHTED_AVERAGE),
+      "Count": (pcr.ReductionType.Count, O.COUNT)}
+OPS = {"Less": pcr.CompareOp.Less, "GreaterEqual": pcr.CompareOp.GreaterEqual, "NotEqual": pcr.CompareOp.NotEqual}
+
+
+def build(seed):
+    rng = np.random.default_rng(5000 + seed)
+    W, H = int(rng.integers(40, 300)), int(rng.integers(40, 260))
+    cs = float(rng.choice([0.5, 1.0, 2.0]))
+    tile = (int(rng.choice([32, 64, 4096])), int(rng.choice([32, 48, 4096])))
+    og = O.make_grid((100.0, -50.0, 100.0 + W * cs, -50.0 + H * cs), cell=(cs, -cs), tile=tile)
+    specs = []
+    for _ in range(int(rng.integers(1, 5))):
+        ch = str(rng.choice(["a", "b"]))
+        kind = str(rng.choice(["point", "point", "gauss", "line"]))
+        if kind == "point":
+            rname = str(rng.choice(list(RT)))
+            specs.append(dict(kind=kind, ch=ch, rname=rname, ogl=None))
+        elif kind == "gauss":
+            rname = str(rng.choice(["Sum", "Average", "WeightedAverage", "Count"]))
+            sig, maxr = float(rng.choice([0.8, 1.5, 3.0])) * cs, float(rng.choice([4.0, 9.0]))
+            specs.append(dict(kind=kind, ch=ch, rname=rname, sigma=sig, maxr=maxr,
+                              ogl=O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sig, sigma_y=sig, max_radius=maxr)))
+        else:
+            rname = str(rng.choice(["Sum", "WeightedAverage", "Count"]))
+            hl = float(rng.uniform(1.0, 9.0)) * cs
+            specs.append(dict(kind=kind, ch=ch, rname=rname, hl=hl, ogl=O.make_glyph(O.GLYPH_LINE, half_length=hl, max_radius=16.0)))
+    filt = None
+    if rng.uniform() < 0.5:
+        filt = ("cls", str(rng.choice(list(OPS))), float(rng.integers(0, 4)))
+    clouds = []
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(100, 8000))
+        clouds.append(dict(x=rng.uniform(og.min_x - cs, og.max_x + cs, n), y=rng.uniform(og.min_y - cs, og.max_y + cs, n),
+                           a=rng.normal(5.0, 2.0, n).astype(np.float32), b=rng.uniform(-1.0, 1.0, n).astype(np.float32),
+                           cls=rng.integers(0, 4, n).astype(np.float32), dir=rng.uniform(0, 6.3, n).astype(np.float32),
+                           device=bool(rng.uniform() < 0.5)))
+    return og, specs, filt, clouds
+
+
+def to_cloud(c):
+    pc = pcr.PointCloud.create(len(c["x"]))
+    pc.set_x_array(c["x"])
+    pc.set_y_array(c["y"])
+    for name in ("a", "b", "cls", "dir"):
+        pc.add_channel(name, pcr.DataType.Float32)
+        pc.set_channel_array_f32(name, c[name])
+    return pc.to_device() if c["device"] else pc
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_mixed_pipeline_matches_oracle(seed):
+    og, specs, filt, clouds = build(seed)
+    cfg = pcr.PipelineConfig()
+    cfg.grid.bounds = pcr.BBox(og.min_x, og.min_y, og.max_x, og.max_y)
+    cfg.grid.cell_size_x, cfg.grid.cell_size_y = og.cell_size_x, og.cell_size_y
+    cfg.grid.tile_width, cfg.grid.tile_height = og.tile_width, og.tile_height
+    cfg.grid.compute_dimensions()
+    assert (cfg.grid.width, cfg.grid.height) == (og.width, og.height)
+    cfg.exec_mode = pcr.ExecutionMode.GPU
+    rs = []
+    for i, s in enumerate(specs):
+        if s["kind"] == "point":
+            r = pcr.ReductionSpec()
+            r.value_channel = s["ch"]
+        elif s["kind"] == "gauss":
+            r = pcr.gaussian_splat_spec(s["ch"], default_sigma=s["sigma"], max_radius_cells=s["maxr"])
+        else:
+            r = pcr.line_splat_spec(s["ch"], direction_channel="dir", default_half_length=s["hl"], max_radius_cells=16.0)
+        r.type = RT[s["rname"]][0]
+        r.output_band_name = f"band{i}"
+        rs.append(r)
+    cfg.reductions = rs
+    if filt:
+        f = pcr.FilterSpec()
+        f.add(filt[0], OPS[filt[1]], filt[2])
+        cfg.filter = f
+    pipe = pcr.Pipeline.create(cfg)
+    assert pipe is not None, pcr.pipeline_create_error()
+    for c in clouds:
+        pipe.ingest(to_cloud(c))
+    pipe.finalize()
+    res = pipe.result()
+    # the oracle sees the surviving points of all ingests at once (reductions are order-independent up to rounding)
+    cat = {k: np.concatenate([c[k] for c in clouds]) for k in ("x", "y", "a", "b", "cls", "dir")}
+    keep = np.ones(len(cat["x"]), dtype=bool)
+    if filt:
+        keep = O.filter_mask(len(cat["x"]), [(cat[filt[0]], filt[1], filt[2])])[0].astype(bool)
+    assert pipe.stats().points_processed == int(keep.sum())
+    for i, s in enumerate(specs):
+        what = f"seed {seed} band {i}: {s['kind']}/{s['rname']} on {s['ch']}"
+        assert res.band_desc(i).name == f"band{i}"
+        got = res.band_array(i)
+        chans = dict(direction=cat["dir"][keep]) if s["kind"] == "line" else {}
+        ort = RT[s["rname"]][1]
+        v = cat[s["ch"]][keep]
+        want = O.run(og, ort, cat["x"][keep], cat["y"][keep], v, glyph=s["ogl"], **chans)
+        gn, wn = np.isnan(got), np.isnan(want)
+        if s["kind"] == "gauss":
+            assert (gn != wn).sum() <= 2, f"{what}: NaN mask"
+        else:
+            assert np.array_equal(gn, wn), f"{what}: NaN mask"
+        both = ~gn & ~wn
+        if s["rname"] in ("Max", "Min") or (s["rname"] == "Count" and s["kind"] != "gauss"):
+            assert np.array_equal(got[both], want[both]), what
+            continue
+        exact = O.run(og, ort, cat["x"][keep], cat["y"][keep], v, glyph=s["ogl"], wide=True, **chans).astype(np.float64)
+        mag = np.abs(exact)
+        if s["rname"] != "Count":
+            mag = np.maximum(mag, np.nan_to_num(O.run(og, ort, cat["x"][keep], cat["y"][keep], np.abs(v), glyph=s["ogl"], wide=True, **chans)))
+        err = np.abs(got[both].astype(np.float64) - exact[both])
+        rtol = 1e-5 if s["kind"] == "point" else 1e-4
+        assert (err <= rtol * np.maximum(1e-2, mag[both])).all(), f"{what}: max err/mag {np.max(err / np.maximum(1e-2, mag[both])):.3g}"
