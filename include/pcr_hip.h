@@ -171,7 +171,10 @@ int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, 
  *      src/engine/accumulator.cpp:33-59) and accumulate_glyph
  *      (include/pcr/engine/glyph_kernels.h:31-42), fused: no sort, no materialised indices. */
 typedef struct pcr_hip_engine pcr_hip_engine;
-/* scratch_bytes = 0: the engine grows its scratch arena on demand. */
+/* scratch_bytes = 0: the engine grows its scratch arena on demand (the arena is shared by all engines of a device).
+ * Test-only environment knobs, read here: PCR_HIP_DEBUG_MAX_BINS=<n> lowers the number of LDS tiles one binning pass
+ * may count (8064) so that the large-grid paths (two-level sort, row bands) are reached on small grids;
+ * PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep where the two-level sort would apply. */
 int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s);
 int pcr_hip_engine_destroy(pcr_hip_engine* e);
 /* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot
