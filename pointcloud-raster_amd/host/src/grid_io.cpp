@@ -512,6 +512,7 @@ size_t type_size(uint16_t t) {
 struct TiffIn {
     FILE* f = nullptr;
     bool big = false;
+    uint64_t file_size = 0;
     std::map<uint16_t, TagIn> tags;
     ~TiffIn() { if (f) std::fclose(f); }
 
@@ -528,7 +529,10 @@ struct TiffIn {
             if (std::fread(h + 8, 1, 8, f) != 8) return Status::error(StatusCode::IoError, "truncated TIFF header");
             std::memcpy(&ifd, h + 8, 8);
         } else return Status::error(StatusCode::IoError, "not a TIFF file: " + path);
-        if (std::fseek(f, (long)ifd, SEEK_SET) != 0) return Status::error(StatusCode::IoError, "bad TIFF directory offset");
+        std::fseek(f, 0, SEEK_END);
+        file_size = (uint64_t)std::ftell(f);
+        if (ifd >= file_size || std::fseek(f, (long)ifd, SEEK_SET) != 0)
+            return Status::error(StatusCode::IoError, "bad TIFF directory offset");
         uint64_t n = 0;
         if (big) { if (std::fread(&n, 8, 1, f) != 1) return bad(); }
         else { uint16_t n16; if (std::fread(&n16, 2, 1, f) != 1) return bad(); n = n16; }
@@ -545,7 +549,7 @@ struct TiffIn {
             if (big) std::memcpy(&count, e + 4, 8);
             else { uint32_t c; std::memcpy(&c, e + 4, 4); count = c; }
             const size_t ts = type_size(type);
-            if (!ts || count > (1ull << 31)) continue;
+            if (!ts || count > file_size / ts) continue;              // a value array cannot be larger than the file
             TagIn t;
             t.type = type;
             t.count = count;
@@ -796,7 +800,8 @@ Status read_geotiff_band(const std::string& path, int band_index, float* data, i
             const int rows = std::min(g.bh, g.H - by * g.bh), cols = std::min(g.bw, g.W - bx * g.bw);
             const int blk_rows = g.tiled ? g.bh : rows;
             const size_t raw_n = (size_t)g.bw * blk_rows * spp * 4;
-            if (!off || !cnt || cnt > (1ull << 31)) return Status::error(StatusCode::IoError, "failed to read band data");
+            if (!off || !cnt || off > t.file_size || cnt > t.file_size - off)
+                return Status::error(StatusCode::IoError, "failed to read band data");
             packed.resize(cnt);
             if (std::fseek(t.f, (long)off, SEEK_SET) != 0 || std::fread(packed.data(), 1, cnt, t.f) != cnt)
                 return Status::error(StatusCode::IoError, "failed to read band data");

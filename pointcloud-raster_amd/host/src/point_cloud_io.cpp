@@ -88,6 +88,17 @@ Status read_pcrp_header(std::ifstream& ifs, const std::string& path, PointCloudI
         header += 2 + name_len + 1;
     }
     if (!ifs) return Status::error(StatusCode::IoError, "failed to read channel table");
+    // the body the header declares must be there (a corrupt point count must not turn into a giant allocation)
+    {
+        const std::streampos here = ifs.tellg();
+        ifs.seekg(0, std::ios::end);
+        const uint64_t actual = (uint64_t)ifs.tellg();
+        ifs.seekg(here);
+        uint64_t row_bytes = 16;
+        for (const auto& c : channels) row_bytes += data_type_size(c.dtype);
+        if (actual < header || num_points > (actual - header) / row_bytes)
+            return Status::error(StatusCode::IoError, "file is shorter than its header declares");
+    }
     info.num_points = num_points;
     info.channels = channels;
     info.crs = CRS();
