@@ -3,35 +3,48 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
-A step = one ingest + finalize of one synthetic cloud that is already resident in HBM, on a
-fresh pre-created pipeline (the reference's protocol creates the pipeline before the clock,
+A step = one ingest + finalize of one synthetic cloud that is already resident in HBM, on a fresh
+pre-created pipeline (the reference's protocol creates the pipeline before the clock,
 scripts/benchmarks/benchmark_glyph_full.py:80-97).  Finalized bands stay in HBM
-(PipelineConfig.result_location = Device); the PCIe-inclusive rates are in DESIGN.md.
+(PipelineConfig.result_location = Device).  Rank 0 prints ONE JSON line.
 
-Default workload = BASELINE.json configs[1] ("C2"): 50 M uniform points, 4096 x 4096 grid,
-Point glyph, Sum + Count + Average on one channel.  With N GPUs the grid is row-block sharded:
-4096 x (4096*N) cells, 50 M points per GPU generated inside that GPU's block (weak scaling).
-Rank 0 prints ONE JSON line.
+N = 1 (default): BASELINE.json configs[1] ("C2"): 50 M uniform points, 4096 x 4096 grid, Point glyph,
+Sum + Count + Average on one channel -- the headline `value`.  The same run also reports
+  per_glyph     Line hl=16 / Gaussian sigma = 1, 4, 16 on the same 50 M points and grid (configs[2] settings;
+                protocol scripts/benchmarks/benchmark_glyph_full.py:92-97,119-133)
+  e2e_host      the drop-in default: host-resident cloud in, host-resident result out (PCIe inside the step)
+  cpu_baseline  the reference's CPU stages (oracle/pcr_cpu_pipeline.cpp) on this box's host cores,
+                1 thread and all cores, on a bounded sample.
+
+N > 1 (default): BASELINE.json configs[4] ("C5"), STRONG scaling: one fixed 16384 x 16384 grid, 1 B uniform
+points in total, row blocks from pcr.distributed.row_block (2048 rows at N = 8: the blocks cut the 4096-row
+reference tiles, so the touched-tile union and -- for Gaussians -- the halo rows really cross RCCL).  Every
+rank generates, on its device, the 1e9/N points of the cloud that fall in its block (seed 42 + rank): points
+arrive routed by y.  `value` = Point / Average; `per_glyph.gauss1` = Gaussian sigma = 1 (r <= 4) / Average in
+the same run.  --unrouted adds `unrouted`: the same Point step when each rank is instead handed an ARBITRARY
+1/N of the cloud and the step includes the device-side partition + all-to-all (pcr.distributed.route_cloud).
+--weak keeps round 1's shape (4096 x 4096*N grid, 50 M points per GPU, tile-aligned blocks, no collective).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 
 import numpy as np
-import torch                      # first: the engine must share torch's HIP runtime
+import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
 import pcr                        # noqa: E402
-from pcr.distributed import ShardedPipeline   # noqa: E402
+from pcr.distributed import ShardedPipeline, row_block   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 
 WORKLOADS = {
-    # name: (description, glyph, reductions, bytes per point of compulsory input traffic)
+    # name: (description, glyph, reductions | sigma | half length, bytes per point of compulsory input traffic)
     "C2": ("50M uniform pts, 4096^2, Point, Sum+Count+Average", "point", ("Sum", "Count", "Average"), 20),
     "point_avg": ("Point, Average", "point", ("Average",), 20),
     "C4": ("clustered (10k hotspots), Point, Max+Min", "point", ("Max", "Min"), 20),
@@ -41,7 +54,10 @@ WORKLOADS = {
     "gauss4": ("Gaussian sigma=4 r<=12 (C3), WeightedAverage", "gauss", 4.0, 20),
     "gauss16": ("Gaussian sigma=16 r<=48, WeightedAverage", "gauss", 16.0, 20),
     "line16": ("Line hl=16 per-point direction (C3), WeightedAverage", "line", 16.0, 24),
+    "C5_point": ("1B uniform pts, 16384^2, Point, Average", "point", ("Average",), 20),
+    "C5_gauss1": ("1B uniform pts, 16384^2, Gaussian sigma=1 r<=4, Average", "gauss", 1.0, 20),
 }
+PER_GLYPH = ("line16", "gauss1", "gauss4", "gauss16")
 
 
 def make_specs(workload):
@@ -55,7 +71,10 @@ def make_specs(workload):
             specs.append(r)
     elif glyph == "gauss":
         max_r = 12.0 if arg == 4.0 else min(4.0 * arg, 64.0)
-        specs.append(pcr.gaussian_splat_spec("value", default_sigma=arg, max_radius_cells=max_r))
+        spec = pcr.gaussian_splat_spec("value", default_sigma=arg, max_radius_cells=max_r)
+        if workload.startswith("C5"):
+            spec.type = pcr.ReductionType.Average                    # configs[4]: "Point + Gaussian sigma=1, Average"
+        specs.append(spec)
     else:
         specs.append(pcr.line_splat_spec("value", direction_channel="direction",
                                          default_half_length=arg, max_radius_cells=arg + 2.0))
@@ -94,29 +113,146 @@ def make_cloud(x, y, v, ch):
     return c
 
 
-def cpu_baseline(workload, G, sample_pts, seed):
-    """The CPU oracle (a single-threaded port of the reference's algorithm, without its sort)
-    timed on this box's host cores on a bounded sample of the same workload."""
+def device_cloud_uniform(n, x_lo, x_hi, y_lo, y_hi, seed):
+    """n uniform points generated ON the device, straight into a device-resident pcr.PointCloud."""
+    c = pcr.PointCloud.create(max(n, 1), pcr.MemoryLocation.Device)
+    if c is None:
+        raise MemoryError("bench: cannot allocate the device cloud")
+    c.add_channel("value", pcr.DataType.Float32)
+    c.resize(n)
+    ptrs = c.device_ptrs()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    for name, typestr, lo, hi in (("x", "<f8", x_lo, x_hi), ("y", "<f8", y_lo, y_hi), ("value", "<f4", 0.0, 1.0)):
+        t = torch.as_tensor(pcr.DeviceArrayView(ptrs[name], (max(n, 1),), typestr, owner=c), device="cuda")
+        t[:n].uniform_(lo, hi, generator=gen)
+    torch.cuda.synchronize()
+    return c
+
+
+def csrc_sha():
+    """Fingerprint of the kernel sources: a PMC traffic figure is only quoted for the kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pointcloud-raster_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
+    """The reference's CPU stages (oracle/pcr_cpu_pipeline.cpp: OpenMP assign, serial std::sort, per-update
+    omp critical, finalize -- one pass per ReductionSpec, as the reference runs them) timed on this box's
+    host cores at 1 thread and at all cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pcr_oracle_py as O
     _, glyph, arg, _ = WORKLOADS[workload]
     x, y, v, ch = make_points(workload, sample_pts, G, 0.0, float(G), seed)
     og = O.make_grid((0.0, 0.0, float(G), float(G)))
-    t0 = time.perf_counter()
+    rmap = {"Sum": O.SUM, "Count": O.COUNT, "Average": O.AVERAGE, "Max": O.MAX, "Min": O.MIN}
     if glyph == "point":
-        for name in arg:                                  # the reference runs one pass per ReductionSpec
-            O.run(og, {"Sum": O.SUM, "Count": O.COUNT, "Average": O.AVERAGE, "Max": O.MAX, "Min": O.MIN}[name], x, y, v)
+        runs = [(rmap[name], None) for name in arg]
     elif glyph == "gauss":
         max_r = 12.0 if arg == 4.0 else min(4.0 * arg, 64.0)
-        O.run(og, O.WEIGHTED_AVERAGE, x, y, v,
-              glyph=O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=arg, sigma_y=arg, max_radius=max_r))
+        runs = [(O.WEIGHTED_AVERAGE, O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=arg, sigma_y=arg, max_radius=max_r))]
     else:
-        O.run(og, O.WEIGHTED_AVERAGE, x, y, v,
-              glyph=O.make_glyph(O.GLYPH_LINE, half_length=arg, max_radius=arg + 2.0), **ch)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_pts / dt / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_pts} pts of the same workload on the {G}^2 grid, ingest+finalize, "
-                      f"{dt:.1f} s, single thread, no sort (oracle/pcr_oracle.c)"}
+        runs = [(O.WEIGHTED_AVERAGE, O.make_glyph(O.GLYPH_LINE, half_length=arg, max_radius=arg + 2.0))]
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    out = {}
+    stages = {}
+    for label, threads in (("1", 1), ("all", ncores)):
+        t0 = time.perf_counter()
+        for rtype, gl in runs:
+            _, st = O.cpu_pipeline_run(og, rtype, x, y, v, glyph=gl, threads=threads, **ch)
+            for k, s in st.items():
+                stages.setdefault(label, {}).setdefault(k, 0.0)
+                stages[label][k] += s
+        dt = time.perf_counter() - t0
+        out[label] = (sample_pts / dt / 1e6, dt)
+        if dt > budget_s and label == "1":             # keep the default run short on a slow host
+            break
+    cal = {}
+    try:
+        with open(os.path.join(ROOT, "oracle", "calibration.json")) as f:
+            cal = json.load(f)["cases"]
+    except (OSError, KeyError, ValueError):
+        pass
+    res = {"value": round(out["1"][0], 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
+           "sample": f"{sample_pts} pts of the same workload on the {G}^2 grid, ingest+finalize of every ReductionSpec, "
+                     f"{out['1'][1]:.1f} s at 1 thread (oracle/pcr_cpu_pipeline.cpp: reference stages incl. its serial sort)",
+           "nproc": ncores,
+           "stage_seconds_1_thread": {k: round(s, 3) for k, s in stages.get("1", {}).items()}}
+    if "all" in out:
+        res["all_cores"] = {"value": round(out["all"][0], 4), "cores": ncores, "seconds": round(out["all"][1], 2),
+                            "note": "every update under omp critical, serial sort: flat or slower with threads, as the "
+                                    "reference (docs/BENCHMARK_RESULTS.md:52-55)"}
+    if cal:
+        res["port_over_reference"] = {k: c["port_over_reference"] for k, c in cal.items()}
+        res["calibration"] = "oracle/calibration.json: port vs the true reference, both timed in the build container"
+    return res
+
+
+def time_steps(pipes, cloud, warmup, world, backend):
+    """W untimed + K timed steps of ingest+finalize; returns (elapsed seconds MAX over ranks, per-kernel ms dict)."""
+    def step(sp):
+        sp.ingest(cloud)
+        sp.finalize()
+
+    for sp in pipes[:warmup]:
+        step(sp)
+    for sp in pipes[warmup:]:
+        sp.pipe.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for sp in pipes[warmup:]:
+        step(sp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernels = {}
+    for sp in pipes[warmup:]:
+        for name, (launches, ms) in sp.pipe.profile_read(True).items():
+            k = kernels.setdefault(name, [0, 0.0])
+            k[0] += launches
+            k[1] += ms
+    return elapsed, kernels
+
+
+def roofline_of(kernels, info, n, bpp, workload, traffic_db):
+    """Dominant kernel by summed HIP-event time; achieved = algorithmic bytes of one launch / its average duration."""
+    if not kernels:
+        return None, None
+    dom = max(kernels, key=lambda k: kernels[k][1])
+    launches, ms = kernels[dom]
+    avg_ms = ms / launches
+    # points one launch of that kernel processes: all of the ingest, except that the binning scatter is two
+    # launches (whole chunks under "k_bin_scatter", the ragged last chunk under "k_bin_scatter_tail")
+    n_launch = n
+    if dom == "k_bin_scatter":
+        chunk = 16384 if info["num_bins"] <= 2048 else 8192
+        n_launch = (n // chunk) * chunk
+    achieved = bpp * n_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None                    # HBM bytes per launch of that kernel from a rocprofv3 PMC run of THESE kernel sources
+    pmc = traffic_db.get(workload, {})
+    if traffic_db.get("csrc_sha") == csrc_sha() and dom in pmc and pmc.get("points_per_launch") == n:
+        traffic = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
+            "algorithmic_bytes_per_launch": bpp * n_launch}
+    return roof, dom
 
 
 def main():
@@ -124,12 +260,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--points", type=int, default=50_000_000, help="points per GPU")
-    ap.add_argument("--grid", type=int, default=4096, help="grid width = rows per GPU")
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU when not square (C5 shard: --grid 16384 --rows 2048)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: C2 on one GPU, C5_point (+ per_glyph gauss1) on several")
+    ap.add_argument("--points", type=int, default=0, help="points per GPU (default 50 M; C5: 1e9 / N)")
+    ap.add_argument("--grid", type=int, default=0, help="grid width (default 4096; C5: 16384)")
+    ap.add_argument("--rows", type=int, default=0, help="--weak only: rows per GPU when not square")
+    ap.add_argument("--weak", action="store_true", help="N > 1: round 1's weak-scaled shape (tile-aligned blocks, no collective)")
     ap.add_argument("--path", default="auto", choices=["auto", "direct", "binned", "moments"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="points of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip the per_glyph / e2e_host legs")
+    ap.add_argument("--unrouted", action="store_true",
+                    help="N > 1: also time the Point step from an UNROUTED cloud (device partition + all-to-all inside the step)")
     ap.add_argument("--host-result", action="store_true", help="finalize into host memory (PCIe-inclusive)")
     ap.add_argument("--host-cloud", action="store_true", help="ingest a host-resident cloud (PCIe-inclusive)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -157,119 +298,190 @@ def main():
         dist.all_reduce(warm)
         dist.barrier()
 
-    G, n = args.grid, args.points
-    R = args.rows if args.rows > 0 else G                  # rows per GPU
-    H = R * world                                          # one R-row block per GPU
-    cfg = pcr.PipelineConfig()
-    cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(H))
-    cfg.grid.cell_size_x, cfg.grid.cell_size_y = 1.0, -1.0
-    cfg.grid.compute_dimensions()
-    cfg.exec_mode = pcr.ExecutionMode.GPU
-    cfg.cuda_device_id = local_rank
-    cfg.reductions = make_specs(args.workload)
-    cfg.result_location = pcr.MemoryLocation.Host if args.host_result else pcr.MemoryLocation.Device
-    cfg.scatter_path = {"auto": 0, "direct": 1, "binned": 2, "moments": 3}[args.path]
-    # scratch arena (routing keys + records) sized at create, outside the clock, as the reference sizes
-    # its MemoryPool in Pipeline::create (src/engine/pipeline.cpp:167-184)
-    cfg.gpu_pool_size_bytes = 16 * n + (64 << 20)
+    strong = world > 1 and not args.weak
+    workload = args.workload or ("C5_point" if strong else "C2")
+    if strong:
+        G = args.grid or 16384
+        H = G
+        n = args.points or 1_000_000_000 // world
+    else:
+        G = args.grid or 4096
+        R = args.rows if args.rows > 0 else G                  # rows per GPU
+        H = R * world                                          # one R-row block per GPU
+        n = args.points or 50_000_000
 
-    # this rank's rows [rank*G, (rank+1)*G) <=> world y in (H - (rank+1)*G, H - rank*G)
-    y_hi = float(H - rank * R)
-    y_lo = y_hi - R
-    x, y, v, ch = make_points(args.workload, n, G, y_lo, y_hi, seed=42 + rank)
-    cloud = make_cloud(x, y, v, ch)
-    if not args.host_cloud:
-        cloud = cloud.to_device()
-    del x, y, v, ch
+    def make_cfg(wl):
+        cfg = pcr.PipelineConfig()
+        cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(H))
+        cfg.grid.cell_size_x, cfg.grid.cell_size_y = 1.0, -1.0
+        cfg.grid.compute_dimensions()
+        cfg.exec_mode = pcr.ExecutionMode.GPU
+        cfg.cuda_device_id = local_rank
+        cfg.reductions = make_specs(wl)
+        cfg.result_location = pcr.MemoryLocation.Host if args.host_result else pcr.MemoryLocation.Device
+        cfg.scatter_path = {"auto": 0, "direct": 1, "binned": 2, "moments": 3}[args.path]
+        # scratch arena (routing keys + records) sized at create, outside the clock, as the reference sizes
+        # its MemoryPool in Pipeline::create (src/engine/pipeline.cpp:167-184)
+        cfg.gpu_pool_size_bytes = 24 * n + (64 << 20)
+        return cfg
 
-    total = args.warmup + args.steps
-    pipes = [ShardedPipeline(cfg, rank, world, device_id=local_rank) for _ in range(total)]
+    # ---- this rank's points ---------------------------------------------------------------------
+    r0, r1 = row_block(rank, world, H)
+    y_hi = float(H - r0)                                       # rows [r0, r1) <=> world y in (H - r1, H - r0)
+    y_lo = float(H - r1)
+    if strong:
+        cloud = device_cloud_uniform(n, 2.0, G - 2.0, y_lo + (2.0 if rank == world - 1 else 0.0),
+                                     y_hi - (2.0 if rank == 0 else 0.0), seed=42 + rank)
+    else:
+        x, y, v, ch = make_points(workload, n, G, y_lo, y_hi, seed=42 + rank)
+        if WORKLOADS[workload][1] != "line" and not args.no_extras and world == 1:
+            ch = dict(ch, direction=np.random.default_rng(4242).uniform(0, np.pi, n).astype(np.float32))   # per_glyph line16
+        host_cloud = make_cloud(x, y, v, ch)
+        cloud = host_cloud if args.host_cloud else host_cloud.to_device()
+        del x, y, v, ch
 
-    def step(sp):
-        sp.ingest(cloud)
-        sp.finalize()
+    def run(wl, steps, warmup, the_cloud=None, cfg_edit=None):
+        cfg = make_cfg(wl)
+        if cfg_edit:
+            cfg_edit(cfg)
+        pipes = [ShardedPipeline(cfg, rank, world, device_id=local_rank) for _ in range(warmup + steps)]
+        elapsed, kernels = time_steps(pipes, the_cloud if the_cloud is not None else cloud, warmup, world, args.backend)
+        info = pipes[-1].pipe.last_scatter()
+        sp = pipes[-1]
+        extra = {"halo_rows": sp.halo, "tiles_local": sp.tiles_local,
+                 "collectives_per_step": dict(zip(("p2p_messages", "all_reduces"), sp.collectives_per_step())),
+                 "halo_bytes_sent_per_step": sp.halo_bytes_per_step()}
+        if world > 1 and not sp.tiles_local:
+            # one extra, separately timed exchange on a finished pipeline (events on the engine stream)
+            dist.barrier()
+            sp.exchange(timed=True)
+            extra["exchange_ms"] = round(sp.exchange_ms, 4)
+        del pipes
+        return elapsed, kernels, info, cfg, extra
 
-    for sp in pipes[:args.warmup]:
-        step(sp)
-    for sp in pipes[args.warmup:]:
-        sp.pipe.profile_enable(True)
+    traffic_db = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic_db = json.load(f)
+    except (OSError, ValueError):
+        pass
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for sp in pipes[args.warmup:]:
-        step(sp)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, kernels, info, cfg, extra = run(workload, args.steps, args.warmup)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-kernel HIP-event times of the timed steps (this rank)
-    kernels = {}
-    for sp in pipes[args.warmup:]:
-        for name, (launches, ms) in sp.pipe.profile_read(True).items():
-            k = kernels.setdefault(name, [0, 0.0])
-            k[0] += launches
-            k[1] += ms
-    info = pipes[-1].pipe.last_scatter()
-
+    out = None
     if rank == 0:
-        desc, glyph, _, bpp = WORKLOADS[args.workload]
+        desc, glyph, _, bpp = WORKLOADS[workload]
         ms_per_step = elapsed / args.steps * 1e3
         value = n * world * args.steps / elapsed / 1e6
         out = {
             "metric": "Mpts/s ingest->finalize",
             "value": round(value, 2), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n,
-                       "grid": f"{G}x{H}", "rows_per_gpu": R, "glyph": glyph,
+            "config": {"workload": f"{workload}: {desc}", "points_per_gpu": n, "points_total": n * world,
+                       "grid": f"{G}x{H}", "rows_per_gpu": r1 - r0, "glyph": glyph,
                        "reductions": [str(r.type).split(".")[-1] for r in cfg.reductions],
                        "scatter_path": info["path"], "lds_tile": list(info["lds_tile"]),
                        "num_bins": info["num_bins"],
-                       "input": "host-resident (H2D inside step)" if args.host_cloud else "device-resident",
+                       "input": ("host-resident (H2D inside step)" if args.host_cloud else "device-resident") +
+                                (", pre-routed by y (each rank holds the points of its row block)" if world > 1 else ""),
                        "result": "host (D2H inside step)" if args.host_result else "device-resident",
-                       "parallelism": f"row-block x{world}"},
+                       "parallelism": f"row-block x{world}", "world_size": world,
+                       "backend": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
+                       "state_init": "planes identity-filled at Pipeline.create, outside the clock (~30 us)",
+                       **extra},
         }
-        if kernels:
-            dom = max(kernels, key=lambda k: kernels[k][1])
-            launches, ms = kernels[dom]
-            avg_ms = ms / launches
-            # points one launch of that kernel processes: all of the ingest, except that the binning scatter is two
-            # launches (whole chunks under "k_bin_scatter", the ragged last chunk under "k_bin_scatter_tail")
-            n_launch = n
-            if dom == "k_bin_scatter":
-                chunk = 16384 if info["num_bins"] <= 2048 else 8192
-                n_launch = (n // chunk) * chunk
-            achieved = bpp * n_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None        # HBM bytes per launch of the dominant kernel, from committed rocprofv3 PMC runs
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    pmc = json.load(f).get(args.workload, {})
-                if dom in pmc and pmc.get("points_per_launch") == n:
-                    traffic = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
-            except OSError:
-                pass
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
-                               "algorithmic_bytes_per_launch": bpp * n_launch}
+        roof, dom = roofline_of(kernels, info, n, bpp, workload, traffic_db)
+        if roof:
+            out["roofline"] = roof
             out["kernels_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in sorted(kernels.items())}
+            # the whole step against the same roof: algorithmic bytes in + finalized bands out
+            step_bytes = bpp * n + 4 * G * (r1 - r0) * len(cfg.reductions)
+            out["step_roofline"] = {"algorithmic_bytes": step_bytes,
+                                    "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                    "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # ---- the rest of the metric, same run ---------------------------------------------------------
+    if not args.no_extras and args.workload is None and not args.host_cloud and not args.host_result:
+        k_extra, w_extra = max(3, min(args.steps, 5)), 1
+        per_glyph = {}
+        for wl in (PER_GLYPH if world == 1 else (("C5_gauss1",) if strong else ())):
+            try:
+                e2, k2, i2, c2, x2 = run(wl, k_extra, w_extra)
+            except Exception as exc:                                   # a failing leg must not cost the headline
+                per_glyph[wl] = {"error": repr(exc)}
+                continue
+            if rank == 0:
+                bpp2 = WORKLOADS[wl][3]
+                roof2, dom2 = roofline_of(k2, i2, n, bpp2, wl, traffic_db)
+                per_glyph[wl.replace("C5_", "")] = {
+                    "workload": WORKLOADS[wl][0], "ms_per_step": round(e2 / k_extra * 1e3, 4),
+                    "Mpts/s": round(n * world * k_extra / e2 / 1e6, 2), "steps": k_extra,
+                    "scatter_path": i2["path"], "dominant_kernel": dom2,
+                    "roofline_frac": roof2["frac"] if roof2 else None,
+                    "kernels_ms_per_step": {k: round(v[1] / k_extra, 4) for k, v in sorted(k2.items())},
+                    **({"exchange": x2} if world > 1 else {})}
+        if rank == 0:
+            out["per_glyph"] = per_glyph
+            base = out["ms_per_step"]
+            if world == 1 and "gauss16" in per_glyph and "ms_per_step" in per_glyph["gauss16"]:
+                out["gauss16_over_point"] = round(per_glyph["gauss16"]["ms_per_step"] / base, 3)
+
+        if world == 1:
+            # the drop-in default: PointCloud.create(n) is Host, result_location defaults to Host
+            try:
+                def host_result(c):
+                    c.result_location = pcr.MemoryLocation.Host
+                e3, _, _, _, _ = run(workload, 3, 1, the_cloud=host_cloud, cfg_edit=host_result)
+                ms3 = e3 / 3 * 1e3
+                moved = 20 * n + 4 * G * H * len(cfg.reductions)
+                out["e2e_host"] = {"ms_per_step": round(ms3, 3), "Mpts/s": round(n / ms3 / 1e3, 2),
+                                   "bytes_over_pcie": moved, "link_GBps": round(moved / ms3 / 1e6, 2),
+                                   "what": "host-resident numpy cloud in (x, y, value staged H2D), host-resident bands out"}
+            except Exception as exc:
+                out["e2e_host"] = {"error": repr(exc)}
+        elif strong and args.unrouted:
+            # the same Point step from an UNROUTED cloud: each rank is handed an arbitrary 1/N of the points (uniform
+            # over the whole grid); device-side partition + all-to-all to the owners are inside the step
+            try:
+                any_cloud = device_cloud_uniform(n, 2.0, G - 2.0, 2.0, H - 2.0, seed=1042 + rank)
+                cfg_u = make_cfg(workload)
+                pipes = [ShardedPipeline(cfg_u, rank, world, device_id=local_rank) for _ in range(1 + 3)]
+                pipes[0].ingest_unrouted(any_cloud)
+                pipes[0].finalize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for sp in pipes[1:]:
+                    sp.ingest_unrouted(any_cloud)
+                    sp.finalize()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                                 device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if rank == 0:
+                    ms_u = float(t.item()) / 3 * 1e3
+                    out["unrouted"] = {"ms_per_step": round(ms_u, 3), "Mpts/s": round(n * world / ms_u / 1e3, 2),
+                                       "what": "each rank handed an arbitrary 1/N of the cloud; step = device partition by "
+                                               "owner + all-to-all of x, y, value (20 B/point, (N-1)/N of them cross xGMI) "
+                                               "+ ingest + exchange + finalize"}
+                del pipes, any_cloud
+            except Exception as exc:
+                if rank == 0:
+                    out["unrouted"] = {"error": repr(exc)}
+
+    if rank == 0:
         sample = args.cpu_sample
         if sample < 0:
-            sample = {"point": 50_000_000, "gauss": 0, "line": 8_000_000}[glyph]          # ~10 s of single-thread CPU work
+            glyph = WORKLOADS[workload][1]
+            sample = {"point": 6_000_000, "gauss": 0, "line": 4_000_000}[glyph]       # a few seconds per thread setting
             if glyph == "gauss":
-                sigma = WORKLOADS[args.workload][2]
-                sample = int(2e9 / (2 * min(3 * sigma, 64) + 1) ** 2 / 4)     # ~10-20 s of cell updates
+                sigma = WORKLOADS[workload][2]
+                sample = max(200_000, int(1e9 / (2 * min(3 * sigma, 64) + 1) ** 2 / 4))
         if world == 1 and sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.workload, G, min(sample, n), seed=42)
+            out["cpu_baseline"] = cpu_baseline(workload, G, min(sample, n), seed=42)
         print(json.dumps(out), flush=True)
 
     if world > 1:

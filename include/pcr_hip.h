@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PCR_HIP_ABI_VERSION 1
+#define PCR_HIP_ABI_VERSION 2
 
 typedef enum pcr_hip_status {
     PCR_HIP_OK = 0,
@@ -142,6 +142,10 @@ int pcr_hip_arena_destroy(pcr_hip_arena* a);
 int pcr_hip_arena_alloc(pcr_hip_arena* a, size_t bytes, void** d_ptr);
 int pcr_hip_arena_reset(pcr_hip_arena* a);
 int pcr_hip_arena_stats(const pcr_hip_arena* a, size_t* capacity, size_t* used, size_t* high_water);
+/* The scatter engine's own scratch (routing keys, records, moment planes) is one such arena per device, shared by
+ * every engine on it, grow-only, borrowed exclusively for the duration of a scatter's enqueue (csrc/engine.hip):
+ * capacity and high-water mark in bytes, number of borrows and of (re)allocations since process start. */
+int pcr_hip_device_scratch_stats(int device, size_t* capacity, size_t* high_water, uint64_t* borrows, uint64_t* grows);
 
 /* ---- state planes.  replaces: init_tile_state / merge_tile_state / finalize_tile,
  *      include/pcr/engine/grid_merge.h:22-41 (src/engine/grid_merge.cu:116-183), and the CPU
@@ -206,6 +210,31 @@ int pcr_hip_filter_mask(const pcr_hip_predicate* preds, int n_pred, uint64_t n, 
                         unsigned long long* d_pass_count, pcr_hip_stream s);
 /* Points with d_mask[i] == 0 are ignored by every following scatter on this engine; NULL clears it. */
 int pcr_hip_engine_set_point_mask(pcr_hip_engine* e, const uint8_t* d_mask);
+
+/* ---- multi-GPU routing of an unpartitioned cloud.  No reference counterpart: the reference is single-device and
+ *      its 1 B-point protocol feeds one pipeline (scripts/benchmarks/benchmark_billion_points.py:221-345).  With the
+ *      grid row-block sharded over GPUs, a rank groups the points it was handed by OWNER (the part whose row range
+ *      holds the point's centre row: GridConfig::world_to_cell, src/core/grid_config.cpp:24-43, exactly as the
+ *      scatter kernels evaluate it), the groups travel point-to-point (RCCL all-to-all, pcr/distributed.py), and
+ *      every rank ingests only points it owns.
+ *   route_count:   d_dest[i] = owning part (0xFF: outside the grid / masked out / owned by nobody);
+ *                  d_counts[p] (device u64, zeroed by the call) = points owned by part p.
+ *                  row_splits: HOST array of nparts+1 ascending rows, part p owns [row_splits[p], row_splits[p+1]).
+ *   route_scatter: regroups up to 8 arrays of 4- or 8-byte elements by owner; d_cursors[p] (device u64) holds the
+ *                  first output slot of part p on entry (exclusive prefix sums of the counts) and is advanced.
+ *                  Order inside a part is unspecified. */
+#define PCR_HIP_MAX_ROUTE_PARTS 64
+#define PCR_HIP_MAX_ROUTE_ARRAYS 8
+int pcr_hip_route_count(const pcr_hip_grid* g, const int32_t* row_splits, int nparts,
+                        const double* d_x, const double* d_y, const uint8_t* d_mask, uint64_t n,
+                        uint8_t* d_dest, unsigned long long* d_counts, pcr_hip_stream s);
+int pcr_hip_route_scatter(const uint8_t* d_dest, uint64_t n, int nparts, unsigned long long* d_cursors,
+                          int narrays, const void* const* d_src, void* const* d_dst, const int32_t* elem_bytes,
+                          pcr_hip_stream s);
+/* max |d_values[i]| over the finite entries (0 for n == 0), synchronizes the stream.  Sizes the halo check of a
+ * row-block shard whose Line glyph has a per-point half_length channel (its y reach is not capped by
+ * max_radius_cells: glyph_kernels.cu:228-234). */
+int pcr_hip_absmax_f32(const float* d_values, uint64_t n, float* h_result, pcr_hip_stream s);
 
 /* Per-kernel timing with HIP events on the engine's stream (for roofline reporting).
  * While enabled every kernel the engine launches is bracketed by two events; _read drains the

@@ -234,3 +234,36 @@ def run(grid, rtype, x, y, value, glyph=None, wide=False, **glyph_channels):
         return r.finalize()
     finally:
         r.close()
+
+
+_cpu = None
+
+
+def cpu_pipeline_lib():
+    """oracle/pcr_cpu_pipeline.cpp: the reference's CPU stages (assign / serial std::sort / per-update
+    `omp critical` / finalize) around the oracle's arithmetic.  Timed by bench.py's cpu_baseline leg."""
+    global _cpu
+    if _cpu is None:
+        path = os.path.join(_HERE, "_build", "libpcr_cpu_pipeline.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        L = C.CDLL(path)
+        L.pcro_cpu_pipeline_run.argtypes = [C.POINTER(Grid), C.c_int, C.POINTER(Glyph), C.POINTER(Points),
+                                            C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        L.pcro_cpu_pipeline_max_threads.restype = C.c_int
+        _cpu = L
+    return _cpu
+
+
+def cpu_pipeline_run(grid, rtype, x, y, value, glyph=None, threads=0, **glyph_channels):
+    """-> (band (H, W) float32, {stage: seconds}).  threads <= 0: OpenMP default (all cores)."""
+    L = cpu_pipeline_lib()
+    pts, keep = make_points(x, y, value, **glyph_channels)
+    band = np.empty((grid.height, grid.width), dtype=np.float32)
+    st = (C.c_double * 5)()
+    gl = glyph if glyph is not None else make_glyph()
+    rc = L.pcro_cpu_pipeline_run(C.byref(grid), rtype, C.byref(gl), C.byref(pts), int(threads), band.ctypes.data, st)
+    del keep
+    if rc != 0:
+        raise OracleError(rc, "pcro_cpu_pipeline_run failed")
+    return band, dict(zip(("assign", "sort", "extract_batches", "accumulate", "finalize"), list(st)))

@@ -12,16 +12,21 @@ using namespace pcrhip;
 namespace {
 
 // One grow-only scratch arena per device, shared by every engine on it (the reference's
-// MemoryPool role, src/engine/memory_pool.cu:24-59).  A scatter borrows it for the kernels it
-// enqueues; ordering between engines on different streams is by event: the borrower's stream
-// waits for the previous borrower's last kernel, so nothing synchronizes the host in steady state
-// and a fresh pipeline never pays a multi-GB hipMalloc on its first ingest.
+// MemoryPool role, src/engine/memory_pool.cu:24-59; the block IS a pcr_hip_arena, the same bump
+// allocator the C-ABI exports).  A scatter borrows the whole arena for the kernels it enqueues:
+//   * ownership is exclusive from ensure_scratch to release_scratch (borrow_mu is held across the two
+//     calls), so two host threads driving two pipelines on one device can never carve the same bytes;
+//   * ordering between borrowers on different streams is by event: the borrower's stream waits for the
+//     previous borrower's last kernel, so nothing synchronizes the host in steady state and a fresh
+//     pipeline never pays a multi-GB hipMalloc on its first ingest;
+//   * the block is only ever replaced by its current owner, after a device-wide synchronize.
 struct SharedScratch {
-    std::mutex mu;
-    char* ptr = nullptr;
-    size_t cap = 0;
+    std::mutex borrow_mu;                 // held while an engine has the arena borrowed
+    std::mutex mu;                        // bookkeeping below
+    pcr_hip_arena* arena = nullptr;
     hipEvent_t last = nullptr;
     bool has_last = false;
+    uint64_t borrows = 0, grows = 0;
 };
 constexpr int kMaxDevices = 64;
 SharedScratch g_scratch[kMaxDevices];
@@ -33,22 +38,38 @@ namespace pcrhip {
 int ensure_scratch(pcr_hip_engine* e, size_t bytes) {
     PCR_REQUIRE(e->device >= 0 && e->device < kMaxDevices, "scratch: device ordinal out of range");
     SharedScratch& sp = g_scratch[e->device];
+    const bool fresh = !e->scratch_borrowed;
+    if (fresh) sp.borrow_mu.lock();                       // released by release_scratch (same host thread)
     std::lock_guard<std::mutex> lock(sp.mu);
-    if (!sp.last) PCR_HIP_TRY(hipEventCreateWithFlags(&sp.last, hipEventDisableTiming));
-    if (bytes > sp.cap) {
-        // growth only (first ingest of a larger size): every earlier user must be done with the old block
-        PCR_HIP_TRY(hipDeviceSynchronize());
-        if (sp.ptr) PCR_HIP_TRY(hipFree(sp.ptr));
-        sp.ptr = nullptr;
-        sp.cap = 0;
+    auto bail = [&](int rc) { if (fresh) sp.borrow_mu.unlock(); return rc; };
+    if (!sp.last && hipEventCreateWithFlags(&sp.last, hipEventDisableTiming) != hipSuccess)
+        return bail(fail(PCR_HIP_CUDA_ERROR, "scratch: cannot create the hand-over event"));
+    size_t cap = 0;
+    if (sp.arena) (void)pcr_hip_arena_stats(sp.arena, &cap, nullptr, nullptr);
+    if (bytes > cap) {
+        // growth only (first ingest of a larger size): every earlier user must be done with the old block,
+        // and nobody else can hold it (we own borrow_mu)
+        if (hipDeviceSynchronize() != hipSuccess) return bail(fail(PCR_HIP_CUDA_ERROR, "scratch: device synchronize failed"));
+        if (sp.arena) (void)pcr_hip_arena_destroy(sp.arena);
+        sp.arena = nullptr;
         sp.has_last = false;
-        size_t want = bytes + bytes / 8;
-        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sp.ptr), want));
-        sp.cap = want;
+        int rc = pcr_hip_arena_create(&sp.arena, bytes + bytes / 8);
+        if (rc) return bail(rc);
+        ++sp.grows;
     }
-    if (sp.has_last && !e->scratch_borrowed) PCR_HIP_TRY(hipStreamWaitEvent(e->stream, sp.last, 0));
-    e->d_scratch = sp.ptr;
-    e->scratch_cap = sp.cap;
+    // one scatter = one allocation that spans what its passes carve up
+    void* base = nullptr;
+    (void)pcr_hip_arena_reset(sp.arena);
+    int rc = pcr_hip_arena_alloc(sp.arena, bytes, &base);
+    if (rc) return bail(rc);
+    if (fresh) {
+        if (sp.has_last && hipStreamWaitEvent(e->stream, sp.last, 0) != hipSuccess)
+            return bail(fail(PCR_HIP_CUDA_ERROR, "scratch: cannot order after the previous borrower"));
+        ++sp.borrows;
+    }
+    (void)pcr_hip_arena_stats(sp.arena, &cap, nullptr, nullptr);
+    e->d_scratch = static_cast<char*>(base);
+    e->scratch_cap = cap;
     e->scratch_borrowed = true;
     return PCR_HIP_OK;
 }
@@ -57,15 +78,31 @@ int ensure_scratch(pcr_hip_engine* e, size_t bytes) {
 void release_scratch(pcr_hip_engine* e) {
     if (!e->scratch_borrowed) return;
     SharedScratch& sp = g_scratch[e->device];
-    std::lock_guard<std::mutex> lock(sp.mu);
-    if (sp.last && hipEventRecord(sp.last, e->stream) == hipSuccess) sp.has_last = true;
-    e->scratch_borrowed = false;
-    e->d_scratch = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(sp.mu);
+        if (sp.last && hipEventRecord(sp.last, e->stream) == hipSuccess) sp.has_last = true;
+        e->scratch_borrowed = false;
+        e->d_scratch = nullptr;
+    }
+    sp.borrow_mu.unlock();
 }
 
 }  // namespace pcrhip
 
 namespace {
+
+// Every entry point that launches or allocates runs on the engine's device, whatever device the
+// calling thread had current (torch, or a second pipeline on another GPU, may have changed it).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 int check_planes(uint32_t mask, const pcr_hip_planes* p, uint32_t allowed, PlanesDev& out) {
     PCR_REQUIRE(p != nullptr, "scatter: null planes");
@@ -133,11 +170,25 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
 
 int pcr_hip_engine_destroy(pcr_hip_engine* e) {
     if (!e) return PCR_HIP_OK;
+    DeviceGuard dev(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (e->d_touched) (void)hipFree(e->d_touched);
     if (e->d_counters) (void)hipFree(e->d_counters);
     delete e;              // the scratch arena is device-wide and outlives engines
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_device_scratch_stats(int device, size_t* capacity, size_t* high_water, uint64_t* borrows, uint64_t* grows) {
+    PCR_REQUIRE(device >= 0 && device < kMaxDevices, "device_scratch_stats: device ordinal out of range");
+    SharedScratch& sp = g_scratch[device];
+    std::lock_guard<std::mutex> lock(sp.mu);
+    size_t cap = 0, hw = 0;
+    if (sp.arena) (void)pcr_hip_arena_stats(sp.arena, &cap, nullptr, &hw);
+    if (capacity) *capacity = cap;
+    if (high_water) *high_water = hw;
+    if (borrows) *borrows = sp.borrows;
+    if (grows) *grows = sp.grows;
     return PCR_HIP_OK;
 }
 
@@ -152,6 +203,7 @@ int pcr_hip_engine_set_path(pcr_hip_engine* e, int path) {
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out) {
     PCR_REQUIRE(e && out, "engine_stats: null argument");
     unsigned long long c[8] = {0};
+    DeviceGuard dev(e->device);
     PCR_HIP_TRY(hipMemcpyAsync(c, e->d_counters, sizeof c, hipMemcpyDeviceToHost, e->stream));
     PCR_HIP_TRY(hipStreamSynchronize(e->stream));
     *out = e->stats;
@@ -181,6 +233,7 @@ int pcr_hip_engine_profile_enable(pcr_hip_engine* e, int on) {
 
 int pcr_hip_engine_profile_read(pcr_hip_engine* e, pcr_hip_kernel_time* out, int capacity, int* count, int reset) {
     PCR_REQUIRE(e && count, "engine_profile_read: null argument");
+    DeviceGuard dev(e->device);
     for (auto& p : e->pending) {
         float ms = 0.0f;
         hipError_t err = hipEventSynchronize(p.b);
@@ -218,6 +271,7 @@ int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_
     PCR_REQUIRE(n < ((uint64_t)1 << 40), "scatter_point: too many points in one call");
     PCR_REQUIRE(d_x && d_y, "scatter_point: null coordinate array");
     PCR_REQUIRE(d_value || plane_mask == PCR_HIP_PLANE_WGT, "scatter_point: null value array");
+    DeviceGuard dev(e->device);
     rc = begin_scatter(e, n);
     if (rc) return rc;
     bool can_bin = binned_point_supported(e, plane_mask);
@@ -259,6 +313,7 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     gl.sigma_x = glyph->d_sigma_x;
     gl.sigma_y = glyph->d_sigma_y;
     gl.rotation = glyph->d_rotation;
+    DeviceGuard dev(e->device);
     rc = begin_scatter(e, n);
     if (rc) return rc;
     if (e->forced_path == 3 || e->forced_path == 0) {

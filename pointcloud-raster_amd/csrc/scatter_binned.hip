@@ -651,7 +651,8 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
 // (16384^2 = 21 888 tiles): level 1 groups the points by runs of 2^s consecutive tiles (about sqrt(tiles)
 // groups), level 2 sorts every group by tile.  Both levels stream; see k_sub_count / k_sub_scatter.
 int two_level_shift(const pcr_hip_engine* e, int tiles) {
-    if (!e->two_level || tiles > kMaxTiles) return 0;
+    // tile kMaxTiles-1 with local cell 2^15-1 would encode to the dropped-point sentinel 0xFFFFFFFF
+    if (!e->two_level || tiles >= kMaxTiles) return 0;
     int s = 1;
     while ((1 << (2 * s)) < tiles) ++s;                                  // groups ~ tiles per group ~ sqrt(tiles)
     while (((tiles + (1 << s) - 1) >> s) > e->max_bins) ++s;

@@ -68,6 +68,12 @@ struct PipelineConfig {
     // is in [shard_row_begin, shard_row_end) and finalizes those rows; -1 = whole grid.
     int shard_row_begin = -1;
     int shard_row_end = -1;
+    // Rows of state kept beyond each side of the owned block (glyph footprints of points near the block edge land
+    // there and are sent to the owning rank).  -1: sized from the glyph defaults (Gaussian: max_radius_cells; Line:
+    // default_half_length / |cell_size_y|, which max_radius_cells does NOT cap on north-up grids).  A Line glyph with a
+    // per-point half_length channel can reach further: ingest() checks every cloud and refuses (InvalidArgument,
+    // naming the rows needed) rather than clip silently -- raise this knob then.  Same value on every rank.
+    int shard_halo_rows = -1;
     int scatter_path = 0;                            // 0 auto, 1 direct atomics, 2 binned LDS tiles, 3 moments+convolution (Gaussian)
 };
 

@@ -175,6 +175,7 @@ struct Pipeline::Impl {
             if (r0 > r1 || r1 > g.height)
                 return Status::error(StatusCode::InvalidArgument, "pipeline: shard row range outside the grid");
             for (const auto& gr : groups) halo = std::max(halo, reach_rows(gr.glyph));
+            halo = std::max(halo, cfg.shard_halo_rows);
             halo = std::min(halo, g.height);
         }
         hg.min_x = g.bounds.min_x; hg.min_y = g.bounds.min_y; hg.max_x = g.bounds.max_x; hg.max_y = g.bounds.max_y;
@@ -220,6 +221,47 @@ struct Pipeline::Impl {
         return 0;
     }
 
+    // A footprint is clipped to the reference tile of its centre cell (Q4): when the owned block is made of whole
+    // tile rows nothing can land outside it, whatever the glyph.
+    bool block_is_whole_tiles() const {
+        const int th = cfg.grid.tile_height;
+        return hg.own_row0 % th == 0 && (hg.own_row1 % th == 0 || hg.own_row1 == hg.height);
+    }
+
+    // Row-block shards: a Line glyph with a per-point half_length channel reaches |hl_i / cell_size_y| rows (+1 for
+    // the rounding of the end points), and on north-up grids max_radius_cells does not cap that (hy < 0 passes
+    // std::min(h, cap) untouched, glyph_kernels.cu:228-234).  Cells beyond the halo would be clipped by the state
+    // window and never reach their owner: refuse instead of returning a grid that differs from the unsharded one.
+    Status check_line_reach(const GlyphSpec& gl, const void* d_half_length, size_t n) {
+        if (gl.type != GlyphType::Line || !d_half_length) return Status::success();
+        if (own_rows() == hg.height || block_is_whole_tiles()) return Status::success();
+        float amax = 0.f;
+        Status s = detail::hip_status(pcr_hip_absmax_f32(static_cast<const float*>(d_half_length), n, &amax, stream));
+        if (!s.ok()) return s;
+        double rows = std::ceil((double)amax / std::fabs(cfg.grid.cell_size_y)) + 1.0;
+        rows = std::min<double>(rows, cfg.grid.tile_height - 1);
+        if (rows > halo)
+            return Status::error(StatusCode::InvalidArgument,
+                "pipeline: a Line segment of this cloud reaches " + std::to_string((long long)rows) +
+                " rows beyond its centre row, but this row-block shard keeps a halo of " + std::to_string(halo) +
+                " rows (sized from default_half_length / max_radius_cells); set PipelineConfig.shard_halo_rows >= " +
+                std::to_string((long long)rows) + " on every rank, or use tile-aligned row blocks");
+        return Status::success();
+    }
+
+    // The pipeline's device is made current for the duration of a call that launches or allocates, whatever the
+    // calling thread had current (torch, another pipeline).
+    struct DeviceScope {
+        int prev = -1;
+        bool changed = false;
+        explicit DeviceScope(int dev) {
+            if (pcr_hip_get_device(&prev) == PCR_HIP_OK && prev != dev) changed = pcr_hip_set_device(dev) == PCR_HIP_OK;
+        }
+        ~DeviceScope() { if (changed) pcr_hip_set_device(prev); }
+        DeviceScope(const DeviceScope&) = delete;
+        DeviceScope& operator=(const DeviceScope&) = delete;
+    };
+
     // Device pointer of a named array of the cloud; host-resident arrays are staged to HBM.
     Status device_array(const void* src, MemoryLocation loc, size_t bytes, const std::string& key,
                         const void** out) {
@@ -241,6 +283,7 @@ struct Pipeline::Impl {
     Status ingest(const PointCloud& cloud, bool wait = true) {
         const size_t n = cloud.count();
         if (n == 0) return Status::success();
+        DeviceScope dev(cfg.cuda_device_id);
         // filter predicates: same checks and messages as filter_points (src/engine/filter.cpp:101-123)
         for (const auto& pr : cfg.filter.predicates) {
             if (!cloud.channel_data(pr.channel_name))
@@ -345,6 +388,7 @@ struct Pipeline::Impl {
                 hgph.d_direction = static_cast<const float*>(p);
                 if (!(s = f32_channel(gr.glyph.half_length_channel, &p)).ok()) return s;
                 hgph.d_half_length = static_cast<const float*>(p);
+                if (!(s = check_line_reach(gr.glyph, p, n)).ok()) return s;
                 if (!(s = f32_channel(gr.glyph.sigma_x_channel, &p)).ok()) return s;
                 hgph.d_sigma_x = static_cast<const float*>(p);
                 if (!(s = f32_channel(gr.glyph.sigma_y_channel, &p)).ok()) return s;
@@ -409,6 +453,7 @@ struct Pipeline::Impl {
         const int W = hg.width;
         if (outputs.empty()) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
         if (rows <= 0) return Status::success();
+        DeviceScope dev(cfg.cuda_device_id);
         const bool on_device = cfg.result_location == MemoryLocation::Device;
         if (!result) {
             Status as = allocate_result();
@@ -522,6 +567,7 @@ struct Pipeline::Impl {
         if (!s.ok()) return s;
         std::vector<std::vector<float>> hp[4];
         std::vector<uint32_t> touched;
+        DeviceScope dev(cfg.cuda_device_id);
         if (!(s = download_state(hp, touched)).ok()) return s;
         const GridConfig& g = cfg.grid;
         const int tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
@@ -562,6 +608,7 @@ struct Pipeline::Impl {
         if (!s.ok()) return s;
         std::vector<std::vector<float>> hp[4];
         std::vector<uint32_t> touched;
+        DeviceScope dev(cfg.cuda_device_id);
         if (!(s = download_state(hp, touched)).ok()) return s;
         const GridConfig& g = cfg.grid;
         const int tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
@@ -622,6 +669,7 @@ struct Pipeline::Impl {
         info.collections_total = 0;
         info.points_processed = points;
         info.tiles_active = 0;
+        DeviceScope dev(cfg.cuda_device_id);
         uint32_t* d_touched = nullptr;
         int tx = 0, ty = 0;
         if (engine && pcr_hip_engine_tile_touched(engine, &d_touched, &tx, &ty) == PCR_HIP_OK) {

@@ -96,6 +96,7 @@ void bind_engine(py::module_& m) {
         .def_readwrite("result_location", &PipelineConfig::result_location)
         .def_readwrite("shard_row_begin", &PipelineConfig::shard_row_begin)
         .def_readwrite("shard_row_end", &PipelineConfig::shard_row_end)
+        .def_readwrite("shard_halo_rows", &PipelineConfig::shard_halo_rows)
         .def_readwrite("scatter_path", &PipelineConfig::scatter_path);
 
     py::class_<ProgressInfo>(m, "ProgressInfo")

@@ -14,6 +14,52 @@ if not _os.path.exists(_lib):
     raise ImportError(f"pcr: {_lib} is not built -- run `python pointcloud-raster_amd/build.py` "
                       "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
 
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process, whatever the import order.
+
+    libpcr_hip.so needs `libamdhip64.so.7`; PyTorch-ROCm bundles its own copy under torch/lib with the same
+    SONAME.  The dynamic loader keeps whichever copy is loaded FIRST for everybody, so `import pcr; import torch`
+    used to run torch on the system runtime and `import torch; import pcr` the engine on torch's.  When torch is
+    installed its copy is loaded here, before the engine: both orders end up on the same runtime, and device
+    pointers, streams and events can be shared between the two (pcr.distributed relies on that)."""
+    import ctypes
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                     # torch's runtime is already the process's runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return                                     # no torch: the system ROCm runtime
+    lib_dir = _os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = _os.path.join(lib_dir, name)
+        if _os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError as exc:                 # loud: a half-shared runtime is the trap this function removes
+                raise ImportError(f"pcr: cannot preload torch's HIP runtime ({path}): {exc}") from exc
+
+
+def hip_runtime_paths():
+    """Paths of every libamdhip64 mapped into this process (diagnostic: more than one is a bug)."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+_share_hip_runtime_with_torch()
+
 from ._pcr import (  # noqa: E402,F401
     BBox, BandDesc, CRS, ChannelDesc, CompareOp, DataType, ExecutionMode, FilterPredicate, FilterSpec,
     GeoTiffOptions, GlyphSpec, GlyphType, Grid, GridConfig, MemoryLocation, NoDataPolicy, Pipeline,
@@ -90,7 +136,7 @@ __all__ = [
     "gaussian_splat_spec", "line_splat_spec",
     "GeoTiffOptions", "write_geotiff", "read_geotiff_info",
     "PointCloudInfo", "read_point_cloud", "write_point_cloud", "read_point_cloud_info", "PointCloudReader",
-    "DeviceArrayView", "device_count", "device_name", "pipeline_create_error",
+    "DeviceArrayView", "hip_runtime_paths", "device_count", "device_name", "pipeline_create_error",
     "read_tile_state", "write_tile_state", "tile_state_filename",
     "read_geotiff_band", "read_geotiff_band_names", "TiledGeoTiffWriter",
 ]

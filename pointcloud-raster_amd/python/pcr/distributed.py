@@ -107,6 +107,111 @@ def allreduce_touched(touched, group=None):
         dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=group)
 
 
+_ELEM_BYTES = {"Float32": 4, "Int32": 4, "UInt32": 4, "Float64": 8}
+_TORCH_DTYPE = {"Float32": torch.float32, "Int32": torch.int32, "UInt32": torch.int32, "Float64": torch.float64}
+_TYPESTR = {"Float32": "<f4", "Int32": "<i4", "UInt32": "<i4", "Float64": "<f8"}
+
+
+def _whole_grid(grid_cfg):
+    """pcr_hip_grid (ctypes) of a pcr.GridConfig, every row owned: the routing decision sees the whole grid."""
+    from . import _cabi as A
+    b = grid_cfg.bounds
+    return A.Grid(b.min_x, b.min_y, b.max_x, b.max_y, grid_cfg.cell_size_x, grid_cfg.cell_size_y,
+                  grid_cfg.width, grid_cfg.height, grid_cfg.tile_width, grid_cfg.tile_height,
+                  0, grid_cfg.height, 0, grid_cfg.height)
+
+
+def partition_cloud(cloud, grid_cfg, blocks, stream=0):
+    """Device-side partition of a device-resident cloud by row-block owner (pcr_hip_route_count /
+    pcr_hip_route_scatter through the C-ABI).
+
+    Returns (counts, arrays): counts[p] = points whose centre row lies in blocks[p] (host list of ints;
+    points outside the grid are dropped, exactly the points the scatter kernels would drop), arrays =
+    {name: (tensor grouped by owner, dtype name)} for "x", "y" and every channel.  Order inside a group
+    is unspecified (the reductions do not depend on it: Count/Min/Max exactly, sums up to fp32 re-association,
+    which the single-GPU atomics already have)."""
+    import ctypes as C
+    import pcr
+    from . import _cabi as A
+    L = A.lib()
+    if cloud.location() != pcr.MemoryLocation.Device:
+        raise ValueError("partition_cloud: the cloud must be device-resident (cloud.to_device())")
+    n = cloud.count()
+    world = len(blocks)
+    if world > 64:
+        raise ValueError("partition_cloud: at most 64 parts")
+    splits = [blocks[0][0]] + [b1 for _, b1 in blocks]
+    for (a0, a1), (b0, _) in zip(blocks, blocks[1:]):
+        if a1 != b0:
+            raise ValueError("partition_cloud: row blocks must be contiguous")
+    names = ["x", "y"] + list(cloud.channel_names())
+    kinds = {"x": "Float64", "y": "Float64"}
+    for name in cloud.channel_names():
+        kind = str(cloud.channel(name).dtype).split(".")[-1]
+        if kind not in _ELEM_BYTES:
+            raise ValueError(f"partition_cloud: channel {name!r} has dtype {kind}; only 4- and 8-byte channels are routed")
+        kinds[name] = kind
+    if len(names) > 8:
+        raise ValueError("partition_cloud: at most 6 channels are routed in one pass")
+    ptrs = cloud.device_ptrs()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dest = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    g = _whole_grid(grid_cfg)
+    c_splits = (C.c_int32 * (world + 1))(*splits)
+    A.check(L.pcr_hip_route_count(C.byref(g), c_splits, world, ptrs["x"], ptrs["y"], None, n,
+                                  dest.data_ptr(), counts.data_ptr(), stream))
+    if stream:
+        A.check(L.pcr_hip_stream_synchronize(stream))
+    h_counts = [int(c) for c in counts.cpu().tolist()]            # synchronizes
+    total = sum(h_counts)
+    cursors = torch.tensor([sum(h_counts[:p]) for p in range(world)], dtype=torch.int64, device=dev)
+    grouped = {}
+    srcs, dsts, elems = [], [], []
+    for name in names:
+        t = torch.empty(max(total, 1), dtype=_TORCH_DTYPE[kinds[name]], device=dev)
+        grouped[name] = (t[:total], kinds[name])
+        srcs.append(ptrs[name])
+        dsts.append(t.data_ptr())
+        elems.append(_ELEM_BYTES[kinds[name]])
+    k = len(names)
+    A.check(L.pcr_hip_route_scatter(dest.data_ptr(), n, world, cursors.data_ptr(), k,
+                                    (C.c_void_p * k)(*srcs), (C.c_void_p * k)(*dsts), (C.c_int32 * k)(*elems), stream))
+    return h_counts, grouped
+
+
+def route_cloud(cloud, grid_cfg, blocks, rank, world, group=None, stream=0):
+    """Routes an arbitrary shard of the cloud to the owners of the row blocks: device-side partition, then one
+    all-to-all per array (RCCL over xGMI; gloo stages through host memory in rehearsals).  Collective: every rank
+    calls it.  Returns a device-resident pcr.PointCloud holding exactly the points whose centre row this rank owns."""
+    import pcr
+    counts, grouped = partition_cloud(cloud, grid_cfg, blocks, stream)
+    stage = dist.get_backend(group) == "gloo"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    send = torch.tensor(counts, dtype=torch.int64, device="cpu" if stage else dev)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_counts = [int(c) for c in recv.cpu().tolist()]
+    total = sum(recv_counts)
+    out = pcr.PointCloud.create(max(total, 1), pcr.MemoryLocation.Device)
+    if out is None:
+        raise MemoryError("route_cloud: cannot allocate the routed cloud on the device")
+    for name in cloud.channel_names():
+        out.add_channel(name, cloud.channel(name).dtype)
+    out.resize(total)
+    optrs = out.device_ptrs()
+    for name, (src, kind) in grouped.items():
+        view = pcr.DeviceArrayView(optrs[name], (max(total, 1),), _TYPESTR[kind], owner=out)
+        dst = torch.as_tensor(view, device="cuda")[:total]
+        if stage:
+            buf = torch.empty(total, dtype=src.dtype)
+            dist.all_to_all_single(buf, src.cpu(), recv_counts, counts, group=group)
+            dst.copy_(buf)
+        else:
+            dist.all_to_all_single(dst, src, recv_counts, counts, group=group)
+    return out
+
+
 class ShardedPipeline:
     """pcr.Pipeline on this rank's row block + the halo exchange.  Usage (one process per GPU):
 
@@ -118,6 +223,8 @@ class ShardedPipeline:
     def __init__(self, cfg, rank, world, device_id=None, align=1, group=None):
         import pcr
         self.rank, self.world, self.group = rank, world, group
+        self.grid = cfg.grid
+        self.exchange_ms = None              # set by exchange(timed=True)
         self.blocks = [row_block(r, world, cfg.grid.height, align) for r in range(world)]
         self.own = self.blocks[rank]
         cfg.shard_row_begin, cfg.shard_row_end = self.own
@@ -148,9 +255,36 @@ class ShardedPipeline:
         return self._views
 
     def ingest(self, cloud):
+        """`cloud` holds (a superset of) the points this rank owns: the engine keeps the points whose centre row is
+        in the owned block and ignores the rest."""
         self.pipe.ingest(cloud)
 
-    def exchange(self):
+    def _engine_stream(self):
+        ptr = self.pipe.stream_ptr()
+        if ptr:
+            return ptr, torch.cuda.stream(torch.cuda.ExternalStream(ptr))
+        self.pipe.synchronize()
+        return 0, torch.cuda.stream(torch.cuda.current_stream())
+
+    def ingest_unrouted(self, cloud):
+        """`cloud` is an ARBITRARY shard of the whole cloud (e.g. one file chunk per rank): its points are grouped
+        by owner on the device, travel to their owners (all-to-all), and each rank ingests what it receives.
+        Collective: every rank calls it once per round, with an empty cloud if it has nothing to contribute."""
+        if self.world == 1:
+            return self.pipe.ingest(cloud)
+        import pcr
+        if cloud.location() != pcr.MemoryLocation.Device:
+            cloud = cloud.to_device()
+        ptr, ctx = self._engine_stream()
+        with ctx:
+            mine = route_cloud(cloud, self.grid, self.blocks, self.rank, self.world, self.group, ptr)
+            if not ptr:
+                torch.cuda.current_stream().synchronize()
+        self.pipe.ingest(mine)
+        self.pipe.synchronize()              # `mine` is freed on return
+        return mine.count()
+
+    def exchange(self, timed=False):
         """Halo reduce + touched-tile union.  No-op for a single rank."""
         # tiles_local: glyph footprints are clipped to the reference tile of their centre cell (Q4), so with
         # tile-aligned blocks nothing ever lands in a neighbour's rows -- no halo to reduce either
@@ -167,16 +301,37 @@ class ShardedPipeline:
             self.pipe.synchronize()
             ctx = torch.cuda.stream(torch.cuda.current_stream())
         with ctx:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if self.halo > 0:
                 exchange_halos(planes, self.own, self.pipe.state_row_begin(), self.halo,
                                self.rank, self.world, blocks=self.blocks, group=self.group)
             if not self.tiles_local:
                 allreduce_touched(self._touched, self.group)
+            if timed:
+                e1.record()
         if not ptr:
             torch.cuda.current_stream().synchronize()
+        if timed:
+            e1.synchronize()
+            self.exchange_ms = e0.elapsed_time(e1)
 
-    def finalize(self):
-        self.exchange()
+    def collectives_per_step(self):
+        """What exchange() issues on this rank: (point-to-point halo messages, all-reduces)."""
+        if self.world == 1 or self.tiles_local:
+            return 0, 0
+        nplanes = len(self.pipe.state_planes())
+        neighbours = (1 if self.rank > 0 else 0) + (1 if self.rank < self.world - 1 else 0)
+        return (2 * neighbours * nplanes if self.halo > 0 else 0), 1
+
+    def halo_bytes_per_step(self):
+        """Bytes this rank SENDS in one exchange: halo rows x width x 4 per plane and neighbour."""
+        p2p, _ = self.collectives_per_step()
+        return (p2p // 2) * self.halo * self.width * 4
+
+    def finalize(self, timed=False):
+        self.exchange(timed)
         self.pipe.finalize()
 
     def result(self):

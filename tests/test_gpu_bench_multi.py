@@ -1,0 +1,51 @@
+"""The N > 1 default of bench.py IS the north-star configuration (BASELINE.json configs[4]: fixed grid, strong scaling,
+row blocks that cut the reference tiles, live halo exchange): rehearsed here with two ranks on one GPU over gloo on a
+down-scaled grid -- the same code path the driver launches with RCCL on 8 GPUs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--same-device"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_default_multi_gpu_bench_is_c5_strong_scaling_with_live_exchange():
+    r = _run(["--grid", "6144", "--points", "3000000", "--unrouted"])      # 2 x 3072 rows: cuts the 4096-row tiles
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
+    c = r["config"]
+    assert c["workload"].startswith("C5_point") and c["grid"] == "6144x6144" and c["rows_per_gpu"] == 3072
+    assert c["points_total"] == 6_000_000 and c["tiles_local"] is False
+    assert c["collectives_per_step"] == {"p2p_messages": 0, "all_reduces": 1}     # Point: touched-tile union only
+    assert c["exchange_ms"] > 0
+    g1 = r["per_glyph"]["gauss1"]
+    assert g1["exchange"]["halo_rows"] == 4 and g1["exchange"]["collectives_per_step"]["p2p_messages"] == 4
+    assert g1["exchange"]["halo_bytes_sent_per_step"] == 2 * 4 * 6144 * 4
+    assert g1["Mpts/s"] > 0 and r["value"] > 0
+    assert r["unrouted"]["Mpts/s"] > 0
+    assert "roofline" in r and r["roofline"]["traffic"] is None or isinstance(r["roofline"]["traffic"], int)
+
+
+def test_weak_flag_keeps_round_one_shape_without_collectives():
+    r = _run(["--weak", "--grid", "1024", "--points", "1000000"])
+    assert r["scaling"] == "weak" and r["config"]["grid"] == "1024x2048"
+    assert r["config"]["tiles_local"] is False or r["config"]["collectives_per_step"]["p2p_messages"] == 0
