@@ -166,15 +166,19 @@ def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
         pass
     out = {}
     stages = {}
-    for label, threads in (("1", 1), ("all", ncores)):
+    # all cores: every update takes the `omp critical` lock, so with many threads the accumulate stage crawls (measured
+    # on the GPU box, 256 threads: 0.06 Mpts/s) -- a much smaller sample keeps the default run short
+    all_pts = min(sample_pts, 150_000 if glyph == "point" else 40_000)
+    for label, threads, m in (("1", 1, sample_pts), ("all", ncores, all_pts)):
+        chm = {k: a[:m] for k, a in ch.items()}
         t0 = time.perf_counter()
         for rtype, gl in runs:
-            _, st = O.cpu_pipeline_run(og, rtype, x, y, v, glyph=gl, threads=threads, **ch)
+            _, st = O.cpu_pipeline_run(og, rtype, x[:m], y[:m], v[:m], glyph=gl, threads=threads, **chm)
             for k, s in st.items():
                 stages.setdefault(label, {}).setdefault(k, 0.0)
                 stages[label][k] += s
         dt = time.perf_counter() - t0
-        out[label] = (sample_pts / dt / 1e6, dt)
+        out[label] = (m / dt / 1e6, dt, m)
         if dt > budget_s and label == "1":             # keep the default run short on a slow host
             break
     cal = {}
@@ -190,6 +194,8 @@ def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
            "stage_seconds_1_thread": {k: round(s, 3) for k, s in stages.get("1", {}).items()}}
     if "all" in out:
         res["all_cores"] = {"value": round(out["all"][0], 4), "cores": ncores, "seconds": round(out["all"][1], 2),
+                            "sample_points": out["all"][2],
+                            "stage_seconds": {k: round(s, 3) for k, s in stages.get("all", {}).items()},
                             "note": "every update under omp critical, serial sort: flat or slower with threads, as the "
                                     "reference (docs/BENCHMARK_RESULTS.md:52-55)"}
     if cal:

@@ -184,6 +184,11 @@ int pcr_hip_engine_destroy(pcr_hip_engine* e);
 /* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot
  * be binned), 3 = force the separable moment + convolution path for Gaussians (other glyphs: as auto) */
 int pcr_hip_engine_set_path(pcr_hip_engine* e, int path);
+/* Hint for the NEXT pcr_hip_scatter_point only (cleared by it): every plane passed to it holds its identity value in
+ * every cell (just filled by pcr_hip_plane_fill / pcr_hip_state_init, nothing accumulated or loaded since).  The
+ * tile-merge pass then stores instead of read-modify-writes (saves one read of the planes).  Wrong hint = wrong
+ * results; the reference initialises tile state on first acquire the same way (src/engine/tile_manager.cpp:272-320). */
+int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh);
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
 /* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */
 int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, int32_t* tiles_x, int32_t* tiles_y);

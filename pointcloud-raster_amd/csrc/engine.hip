@@ -200,6 +200,12 @@ int pcr_hip_engine_set_path(pcr_hip_engine* e, int path) {
     return PCR_HIP_OK;
 }
 
+int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh) {
+    PCR_REQUIRE(e, "engine_planes_fresh: null engine");
+    e->planes_fresh = fresh != 0;
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out) {
     PCR_REQUIRE(e && out, "engine_stats: null argument");
     unsigned long long c[8] = {0};
@@ -277,8 +283,12 @@ int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_
     bool can_bin = binned_point_supported(e, plane_mask);
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: binned path forced but not applicable to this grid");
-    if (e->forced_path == 1 || !can_bin) return direct_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    if (e->forced_path == 1 || !can_bin) {
+        e->planes_fresh = false;
+        return direct_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    }
     rc = binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
+    e->planes_fresh = false;                              // the hint covers one scatter
     release_scratch(e);
     return rc;
 }
@@ -314,6 +324,7 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     gl.sigma_y = glyph->d_sigma_y;
     gl.rotation = glyph->d_rotation;
     DeviceGuard dev(e->device);
+    e->planes_fresh = false;                              // glyph merges always accumulate
     rc = begin_scatter(e, n);
     if (rc) return rc;
     if (e->forced_path == 3 || e->forced_path == 0) {

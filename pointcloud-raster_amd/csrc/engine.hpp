@@ -22,6 +22,7 @@ struct pcr_hip_engine {
                                                // so that tests reach the large-grid paths on small grids)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
     pcr_hip_scatter_stats stats{};
+    bool planes_fresh = false;                 // pcr_hip_engine_planes_fresh: the NEXT scatter's planes hold identity values
 
     // optional per-kernel event timing
     bool profiling = false;

@@ -48,12 +48,16 @@ __device__ __forceinline__ Routed route(const GridDev& g, const BinGeom& b, doub
 }
 
 // ---- pass A: routing keys + histogram -------------------------------------------------------
-__global__ void __launch_bounds__(kThreads)
+// 512-thread workgroups: the kernel needs ~106 SGPRs (7 waves per SIMD), so 1024-thread groups ran one per CU;
+// three 512-thread groups per CU keep half as many loads again in flight.
+constexpr int kCountThreads = 512;
+
+__global__ void __launch_bounds__(kCountThreads)
 k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
             uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
             uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
     extern __shared__ unsigned lds_hist[];
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) lds_hist[i] = 0;
+    for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
@@ -79,23 +83,23 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         const double2* y2 = reinterpret_cast<const double2*>(y + base);
         uint2* k2 = reinterpret_cast<uint2*>(keys + base);
         const int pairs = b.chunk >> 1;
-        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kThreads) {
+        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kCountThreads) {
             double2 xs[4], ys[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                xs[u] = x2[p0 + u * kThreads];
-                ys[u] = y2[p0 + u * kThreads];
+                xs[u] = x2[p0 + u * kCountThreads];
+                ys[u] = y2[p0 + u * kCountThreads];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint64_t i = base + 2ull * (p0 + u * kThreads);
+                const uint64_t i = base + 2ull * (p0 + u * kCountThreads);
                 unsigned ka = handle(i, xs[u].x, ys[u].x);
                 unsigned kb = handle(i + 1, xs[u].y, ys[u].y);
-                k2[p0 + u * kThreads] = make_uint2(ka, kb);
+                k2[p0 + u * kCountThreads] = make_uint2(ka, kb);
             }
         }
     } else {
-        for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
+        for (int k = threadIdx.x; k < b.chunk; k += kCountThreads) {
             uint64_t i = base + k;
             if (i >= n) break;
             keys[i] = handle(i, x[i], y[i]);
@@ -103,7 +107,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
     __syncthreads();
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) {
+    for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) {
         unsigned c = lds_hist[i];
         if (c) atomicAdd(&bin_count[i], c);
     }
@@ -158,33 +162,48 @@ k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_co
 }
 
 // ---- pass B: scatter records, staged through LDS so that every bin's run is written contiguously
+//
+// One workgroup = 512 threads x PER_THREAD points = one chunk (16384 or 8192 points).  The chunk is ranked by
+// bin with LDS atomics, bins are scanned, every non-empty (block, bin) run reserves its place in the bin's
+// global range with ONE atomic, and the records leave through an LDS staging WINDOW of kStageWindow records
+// (64 KB): round r stages the records whose position inside the block's sorted order falls in
+// [r * window, (r + 1) * window) and writes them out.  Positions, not bins, define the rounds, so a skewed chunk
+// costs nothing extra.  Round 1 staged the whole chunk (128 KB): one workgroup per CU, and every phase of it
+// (load / rank / reserve / stage / write) ran with nothing else to overlap -- 60 % of the wave-cycles waited
+// (profiles/r01_c2_sq_counters.md).  With the window two workgroups share a CU (2 x (64 KB + 8 B per bin)),
+// runs stay as long as before (they depend on the chunk, not on the window), and one workgroup's loads and stores
+// overlap the other's LDS phases.
 // VEC: every block of the launch is a full chunk and keys/v are 16-byte aligned (16-byte loads,
 // four consecutive points per lane); the ragged last chunk is a second, scalar launch.
 // INDEX: record.y = index of the point instead of its value (Gaussian tiles: LDS-atomic bound, the gather is free).
+constexpr int kScatterThreads = 512;
+constexpr int kStageWindow = 8192;              // records staged per round
+
 template <int PER_THREAD, bool VEC, bool INDEX>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kScatterThreads, 4)
 k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, const float* __restrict__ v,
               uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
     extern __shared__ unsigned char lds_raw[];
-    // layout: stage[chunk] (8 B each) | hist[nbins] | loff[nbins]; after the scan hist[bin] is reused for
-    // (global start of the block's run) - loff[bin], so that a staged record j goes to hist[bin] + j
+    // layout: stage[window] (8 B each) | hist[nbins] | loff[nbins]; after the scan hist[bin] is reused for
+    // (global start of the block's run) - loff[bin], so that the record at sorted position j goes to hist[bin] + j
     uint2* stage = reinterpret_cast<uint2*>(lds_raw);
-    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)b.chunk * sizeof(uint2));
+    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)kStageWindow * sizeof(uint2));
     unsigned* loff = hist + b.nbins;
-    __shared__ unsigned wave_tot[kThreads / 64];
+    constexpr int kWaves = kScatterThreads / 64;
+    __shared__ unsigned wave_tot[kWaves];
 
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
+    for (int i = threadIdx.x; i < b.nbins; i += kScatterThreads) hist[i] = 0;
     __syncthreads();
     const int gshift = kLcellBits + b.sup_shift;          // key -> bin of this pass (a tile, or a group of tiles)
 
-    const uint64_t base = (uint64_t)(blockIdx.x + first_block) * b.chunk;
-    unsigned key[PER_THREAD], rank[PER_THREAD], val[PER_THREAD];
+    const uint64_t base = (uint64_t)(blockIdx.x + first_block) * (kScatterThreads * PER_THREAD);
+    unsigned key[PER_THREAD], pos[PER_THREAD], val[PER_THREAD];
     if (VEC) {
         const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
         const uint4* v4 = reinterpret_cast<const uint4*>(v + base);
 #pragma unroll
         for (int q = 0; q < PER_THREAD / 4; ++q) {
-            const unsigned p = q * kThreads + threadIdx.x;
+            const unsigned p = q * kScatterThreads + threadIdx.x;
             uint4 kk = k4[p];
             key[4 * q + 0] = kk.x; key[4 * q + 1] = kk.y; key[4 * q + 2] = kk.z; key[4 * q + 3] = kk.w;
             if (INDEX) {
@@ -198,7 +217,7 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     } else {
 #pragma unroll
         for (int k = 0; k < PER_THREAD; ++k) {
-            uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
+            uint64_t i = base + (uint64_t)k * kScatterThreads + threadIdx.x;
             key[k] = 0xFFFFFFFFu;
             val[k] = 0u;
             if (i < n) {
@@ -210,13 +229,13 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     }
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
-        rank[k] = 0;
-        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> gshift], 1u);       // rank inside (block, bin)
+        pos[k] = 0;
+        if (key[k] != 0xFFFFFFFFu) pos[k] = atomicAdd(&hist[key[k] >> gshift], 1u);       // rank inside (block, bin)
     }
     __syncthreads();
 
     // block-wide exclusive scan of hist -> loff; reserve global ranges per non-empty bin
-    const int per = (b.nbins + kThreads - 1) / kThreads;       // <= 4
+    const int per = (b.nbins + kScatterThreads - 1) / kScatterThreads;
     const int lo = threadIdx.x * per, hi = min(lo + per, b.nbins);
     unsigned s = 0;
     for (int i = lo; i < hi; ++i) s += hist[i];
@@ -239,25 +258,31 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
         run += c;
     }
     unsigned total = 0;
-    for (int w = 0; w < kThreads / 64; ++w) total += wave_tot[w];
+    for (int w = 0; w < kWaves; ++w) total += wave_tot[w];
     __syncthreads();
 
-    // stage records grouped by bin
+    // rank inside the bin -> position inside the block's sorted order
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k) {
-        if (key[k] != 0xFFFFFFFFu) {
-            unsigned bin = key[k] >> gshift;
-            stage[loff[bin] + rank[k]] = make_uint2(key[k], val[k]);
-        }
-    }
-    __syncthreads();
+    for (int k = 0; k < PER_THREAD; ++k)
+        if (key[k] != 0xFFFFFFFFu) pos[k] += loff[key[k] >> gshift];
 
-    // write out: consecutive staged records of a bin go to consecutive global slots
-    for (unsigned j = threadIdx.x; j < total; j += kThreads) {
-        uint2 rec = stage[j];
-        unsigned bin = rec.x >> gshift;
-        unsigned dst = hist[bin] + j;
-        records[dst] = make_uint2(b.sup_shift ? rec.x : rec.x & kLcellMask, rec.y);   // first of two levels: keep the tile
+    for (unsigned w0 = 0; w0 < total; w0 += kStageWindow) {
+        // stage the records of this window, grouped by bin
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) {
+            const unsigned rel = pos[k] - w0;                  // wraps for positions before the window
+            if (key[k] != 0xFFFFFFFFu && rel < (unsigned)kStageWindow) stage[rel] = make_uint2(key[k], val[k]);
+        }
+        __syncthreads();
+        // write out: consecutive staged records of a bin go to consecutive global slots
+        const unsigned cnt = min((unsigned)kStageWindow, total - w0);
+        for (unsigned j = threadIdx.x; j < cnt; j += kScatterThreads) {
+            uint2 rec = stage[j];
+            unsigned bin = rec.x >> gshift;
+            unsigned dst = hist[bin] + w0 + j;
+            records[dst] = make_uint2(b.sup_shift ? rec.x : rec.x & kLcellMask, rec.y);   // first of two levels: keep the tile
+        }
+        __syncthreads();
     }
 }
 
@@ -449,7 +474,7 @@ inline BinGeom point_bin_geom(const GridDev& g, uint32_t mask, int row0, int row
 template <unsigned MASK>
 __global__ void __launch_bounds__(kThreads)
 k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ records,
-             const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
+             const BinItem* __restrict__ items, const unsigned* __restrict__ n_items, int fresh) {
     extern __shared__ double lds_tile[];
     if (blockIdx.x >= *n_items) return;
     const BinItem it = items[blockIdx.x];
@@ -459,6 +484,21 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
     float* t_max = reinterpret_cast<float*>(t_wgt + ((MASK & 2) ? cells : 0));
     float* t_min = t_max + ((MASK & 4) ? cells : 0);
 
+    // records: kUnroll independent 8-byte loads per lane, double-buffered -- the next batch is in flight
+    // (64 KB per CU) while the current one goes through the dependent LDS atomics, and the first batch is
+    // issued before the tile is even initialised.
+    constexpr int kUnroll = 8;
+    const uint2* rec = records + it.first;
+    uint2 cur[kUnroll], nxt[kUnroll];
+    auto fetch = [&](uint2 (&r)[kUnroll], unsigned j0) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const unsigned j = j0 + u * kThreads;
+            r[u] = j < it.count ? rec[j] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+    };
+    fetch(cur, threadIdx.x);
+
     for (int i = threadIdx.x; i < cells; i += kThreads) {      // identity fill
         if (MASK & 1) t_sum[i] = 0.0;
         if (MASK & 2) t_wgt[i] = 0u;
@@ -467,26 +507,19 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
     }
     __syncthreads();
 
-    // records: kUnroll independent 8-byte loads in flight per lane (64 KB per CU) ahead of the
-    // dependent LDS atomics
-    constexpr int kUnroll = 8;
-    const uint2* rec = records + it.first;
     for (unsigned j0 = threadIdx.x; j0 < it.count; j0 += kUnroll * kThreads) {
-        uint2 r[kUnroll];
+        fetch(nxt, j0 + kUnroll * kThreads);                    // past the end: sentinels, no loads issued
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            unsigned j = j0 + u * kThreads;
-            r[u] = j < it.count ? rec[j] : make_uint2(0xFFFFFFFFu, 0u);
+            if (cur[u].x == 0xFFFFFFFFu) continue;
+            float val = __uint_as_float(cur[u].y);
+            if (MASK & 1) unsafeAtomicAdd(&t_sum[cur[u].x], (double)val);
+            if (MASK & 2) atomicAdd(&t_wgt[cur[u].x], 1u);
+            if (MASK & 4) atomic_max_f32(&t_max[cur[u].x], val);
+            if (MASK & 8) atomic_min_f32(&t_min[cur[u].x], val);
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            if (r[u].x == 0xFFFFFFFFu) continue;
-            float val = __uint_as_float(r[u].y);
-            if (MASK & 1) unsafeAtomicAdd(&t_sum[r[u].x], (double)val);
-            if (MASK & 2) atomicAdd(&t_wgt[r[u].x], 1u);
-            if (MASK & 4) atomic_max_f32(&t_max[r[u].x], val);
-            if (MASK & 8) atomic_min_f32(&t_min[r[u].x], val);
-        }
+        for (int u = 0; u < kUnroll; ++u) cur[u] = nxt[u];
     }
     __syncthreads();
 
@@ -520,10 +553,18 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
             }
             if (MASK & 4) { a4 = *reinterpret_cast<const float4*>(t_max + li); n4 = (a4.x != -FLT_MAX) | (a4.y != -FLT_MAX) | (a4.z != -FLT_MAX) | (a4.w != -FLT_MAX); }
             if (MASK & 8) { a8 = *reinterpret_cast<const float4*>(t_min + li); n8 = (a8.x != FLT_MAX) | (a8.y != FLT_MAX) | (a8.z != FLT_MAX) | (a8.w != FLT_MAX); }
-            if ((MASK & 1) && n1) g1 = *reinterpret_cast<const float4*>(pl.sum + cell);
-            if ((MASK & 2) && n2) g2 = *reinterpret_cast<const float4*>(pl.wgt + cell);
-            if ((MASK & 4) && n4) g4 = *reinterpret_cast<const float4*>(pl.mx + cell);
-            if ((MASK & 8) && n8) g8 = *reinterpret_cast<const float4*>(pl.mn + cell);
+            if (fresh) {
+                // the planes hold their identity values (first scatter into them): nothing to read
+                if (MASK & 1) g1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MASK & 2) g2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MASK & 4) g4 = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+                if (MASK & 8) g8 = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+            } else {
+                if ((MASK & 1) && n1) g1 = *reinterpret_cast<const float4*>(pl.sum + cell);
+                if ((MASK & 2) && n2) g2 = *reinterpret_cast<const float4*>(pl.wgt + cell);
+                if ((MASK & 4) && n4) g4 = *reinterpret_cast<const float4*>(pl.mx + cell);
+                if ((MASK & 8) && n8) g8 = *reinterpret_cast<const float4*>(pl.mn + cell);
+            }
             if ((MASK & 1) && n1) { g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w; *reinterpret_cast<float4*>(pl.sum + cell) = g1; }
             if ((MASK & 2) && n2) { g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w; *reinterpret_cast<float4*>(pl.wgt + cell) = g2; }
             if ((MASK & 4) && n4) { g4.x = fmaxf(g4.x, a4.x); g4.y = fmaxf(g4.y, a4.y); g4.z = fmaxf(g4.z, a4.z); g4.w = fmaxf(g4.w, a4.w); *reinterpret_cast<float4*>(pl.mx + cell) = g4; }
@@ -555,8 +596,9 @@ void launch_accum(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const 
     size_t lds = (size_t)b.tile_w * b.tile_h * tile_cell_bytes(MASK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_accum<MASK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // fresh: only when every bin is owned by one workgroup of this launch can a store replace the read-modify-write
     hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, b, pl,
-                       bb.records, bb.items, bb.n_items);
+                       bb.records, bb.items, bb.n_items, e->planes_fresh ? 1 : 0);
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -590,7 +632,7 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream,
+        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
                            gd, b, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
@@ -611,7 +653,7 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         out->grecords = d_rec;
     } else {
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
-        const size_t lds = (size_t)b.chunk * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
+        const size_t lds = (size_t)kStageWindow * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
         const bool index_records = kind == RecordKind::Index;
         const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;   // d_keys is 256-B aligned
         const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
@@ -621,21 +663,21 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
             ScopedKernelTimer t(e, name);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, b, first, d_keys, v, n,
+            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kScatterThreads), lds, e->stream, b, first, d_keys, v, n,
                                d_cursor, d_rec);
         };
         if (b.chunk == 16384 && !index_records) {
+            launch("k_bin_scatter", &k_bin_scatter<32, true, false>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, false>, blocks - full_blocks, full_blocks);
+        } else if (b.chunk == 16384) {
+            launch("k_bin_scatter", &k_bin_scatter<32, true, true>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, true>, blocks - full_blocks, full_blocks);
+        } else if (!index_records) {
             launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
             launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
-        } else if (b.chunk == 16384) {
+        } else {
             launch("k_bin_scatter", &k_bin_scatter<16, true, true>, full_blocks, 0);
             launch("k_bin_scatter_tail", &k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
-        } else if (!index_records) {
-            launch("k_bin_scatter", &k_bin_scatter<8, true, false>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
-        } else {
-            launch("k_bin_scatter", &k_bin_scatter<8, true, true>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
         }
         out->records = d_rec;
         out->grecords = nullptr;
@@ -689,7 +731,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     PCR_HIP_TRY(hipMemsetAsync(U(o_count2), 0, (size_t)tiles.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kThreads), (size_t)l1.nbins * 4, e->stream,
+        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
                            e->gd, l1, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
     }
     {
@@ -698,27 +740,27 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
                            U(o_cursor1), d_items1, U(o_nitems1));
     }
     {
-        const size_t lds = (size_t)l1.chunk * sizeof(uint2) + (size_t)l1.nbins * 4 * 2;
+        const size_t lds = (size_t)kStageWindow * sizeof(uint2) + (size_t)l1.nbins * 4 * 2;
         const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;
         const int full_blocks = aligned ? (int)(n / l1.chunk) : 0;
         auto launch = [&](const char* name, auto kernel, int nblocks, int first) {
             if (nblocks <= 0) return;
             ScopedKernelTimer t(e, name);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kThreads), lds, e->stream, l1, first, U(o_keys), v, n, U(o_cursor1), d_rec1);
+            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kScatterThreads), lds, e->stream, l1, first, U(o_keys), v, n, U(o_cursor1), d_rec1);
         };
         if (l1.chunk == 16384 && !index_records) {
+            launch("k_bin_scatter", &k_bin_scatter<32, true, false>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, false>, blocks - full_blocks, full_blocks);
+        } else if (l1.chunk == 16384) {
+            launch("k_bin_scatter", &k_bin_scatter<32, true, true>, full_blocks, 0);
+            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, true>, blocks - full_blocks, full_blocks);
+        } else if (!index_records) {
             launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
             launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
-        } else if (l1.chunk == 16384) {
+        } else {
             launch("k_bin_scatter", &k_bin_scatter<16, true, true>, full_blocks, 0);
             launch("k_bin_scatter_tail", &k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
-        } else if (!index_records) {
-            launch("k_bin_scatter", &k_bin_scatter<8, true, false>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, false>, blocks - full_blocks, full_blocks);
-        } else {
-            launch("k_bin_scatter", &k_bin_scatter<8, true, true>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<8, false, true>, blocks - full_blocks, full_blocks);
         }
     }
     const int tps = 1 << tiles.sup_shift;

@@ -9,8 +9,8 @@
 //
 // where c_k(z) are the Chebyshev coefficients of s' -> exp(z s') on [-1/2, 1/2] (c_k ~ 2 (z/4)^k / k!: they
 // fall 2^(k-1) times faster than the Taylor terms (z/2)^k / k!, and |T_k| <= 1 makes the tail bound rigorous).
-// |z| <= (r + 1/2)/sigma^2 is small for sigma >= 2 cells, so a total order K of 4 (sigma=16) to 9 (sigma=2)
-// reproduces every weight to <= 1e-5 relative (bound in make_plan; measured ~1e-6 in tests).  Then
+// |z| <= (r + 1/2)/sigma^2 is small for sigma >= 2 cells, so a total order K of 3 (sigma=16) to 9 (sigma=2)
+// reproduces every weight to <= 5e-5 relative (rigorous bound in make_plan; half the 1e-4 test tolerance).  Then
 //
 //   splat = sum_{k+l<=K} (A_k (x) B_l) * M_kl ,   M_kl[cell] = sum_{points centred in cell} v m_k(s'x) n_l(s'y)
 //
@@ -42,6 +42,7 @@ constexpr int kTileW = 128, kTileH = 72;                 // 9216 cells: two u32 
 constexpr int kTileCells = kTileW * kTileH;
 constexpr int kSortChunk = 32768;                        // records sorted per round inside LDS (u16 positions: 64 KB)
 constexpr int kMaxK = 9;
+constexpr double kTruncationBound = 5e-5;      // make_plan: rigorous bound on the relative error of any weight
 
 struct MomPlan {
     BinGeom bins;
@@ -753,19 +754,22 @@ bool make_plan(const GridDev& g, const GlyphDev& gl, MomPlan* out) {
     // Total order K: the dropped terms are sum_{k+l>K} c_k(zx) T_k c_l(zy) T_l, |T| <= 1, so relative to the true
     // factor exp(zx s'x + zy s'y) >= exp(-(zx+zy)/2) the error of a weight is <= e^((zx+zy)/2) sum_{k+l>K} |c_k||c_l|,
     // largest at the rim of the footprint (zx = (r+1/2)/sx^2, where the weight itself is ~1 % of the peak).  K is the
-    // smallest instantiated order whose bound is <= 1e-5, a tenth of the 1e-4 tolerance every Gaussian path is tested to.
+    // smallest instantiated order whose bound is <= kTruncationBound = 5e-5.  Every weight of a cell's sum is positive and
+    // carries at most that relative error, so the sum does too: half of the 1e-4 tolerance every Gaussian path is
+    // tested to, the other half being ~20x the float32 accumulation noise.  (Round 1 asked for 1e-5: order 4 at
+    // sigma = 16, whose bound is 3e-7 -- fifteen moment planes where ten do: order 3 bounds at 1.6e-5.)
     const double zx = (r + 0.5) / sx2, zy = (r + 0.5) / sy2;
     constexpr int kTail = 40;
     double cx[kTail + 1], cy[kTail + 1];
     cheb_coeffs(zx, kTail, cx);
     cheb_coeffs(zy, kTail, cy);
     int K = -1;
-    for (int cand : {4, 5, 6, 7, 9}) {
+    for (int cand : {3, 4, 5, 6, 7, 9}) {
         double tail = 0.0;
         for (int k = 0; k <= kTail; ++k)
             for (int l = 0; l <= kTail; ++l)
                 if (k + l > cand) tail += std::fabs(cx[k]) * std::fabs(cy[l]);
-        if (std::exp(0.5 * (zx + zy)) * tail <= 1e-5) { K = cand; break; }
+        if (std::exp(0.5 * (zx + zy)) * tail <= kTruncationBound) { K = cand; break; }
     }
     if (K < 0) return false;
     MomPlan p;
@@ -838,7 +842,8 @@ void launch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, cons
 template <unsigned MASK>
 void dispatch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                       float* mom_v, float* mom_w, int64_t stride) {
-    if (p.K == 4) launch_moments<4, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
+    if (p.K == 3) launch_moments<3, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
+    else if (p.K == 4) launch_moments<4, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
     else if (p.K == 5) launch_moments<5, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
     else if (p.K == 6) launch_moments<6, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);
     else if (p.K == 7) launch_moments<7, MASK>(e, gw, p, rec, bin_start, mom_v, mom_w, stride);

@@ -123,6 +123,8 @@ public:
         void* device_ptr;      // first float of the plane (row state_row_begin)
         int plane_kind;        // PCR_HIP_PLANE_* of include/pcr_hip.h
         int group;             // accumulation group index
+        int reach_rows;        // rows the group's glyph can reach beyond a point's centre row (0: Point glyph -- its halo
+                               // rows never receive anything and need no exchange)
     };
     int halo_rows() const;                       // rows kept above/below the owned block
     int state_row_begin() const;

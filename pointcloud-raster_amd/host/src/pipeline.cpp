@@ -81,6 +81,7 @@ struct Pipeline::Impl {
         uint32_t mask = 0;
         detail::Buffer planes[4];
         pcr_hip_planes view{};
+        bool fresh = true;               // planes still hold their identity fill: the first Point merge may store
     };
     struct Output {                      // one ReductionSpec -> one band
         int group = 0;
@@ -371,6 +372,8 @@ struct Pipeline::Impl {
             s = f32_channel(gr.value_channel, &dv);
             if (!s.ok()) return s;
             if (gr.glyph.type == GlyphType::Point) {
+                if (gr.fresh) pcr_hip_engine_planes_fresh(engine, 1);
+                gr.fresh = false;
                 s = detail::hip_status(pcr_hip_scatter_point(
                     engine, gr.mask, &gr.view, static_cast<const double*>(dx), static_cast<const double*>(dy),
                     static_cast<const float*>(dv), n));
@@ -400,6 +403,7 @@ struct Pipeline::Impl {
                     static_cast<const double*>(dx), static_cast<const double*>(dy),
                     static_cast<const float*>(dv), n));
             }
+            gr.fresh = false;
             if (!s.ok()) return s;
         }
         // host arrays may be reused by the caller as soon as we return (ingest_async: page-locked arrays are
@@ -649,6 +653,7 @@ struct Pipeline::Impl {
                 }
         }
         if (!loaded) return Status::success();
+        for (auto& gr : groups) gr.fresh = false;
         const size_t cells = (size_t)g.width * g.height;
         for (size_t gi = 0; gi < groups.size(); ++gi)
             for (int p = 0; p < 4; ++p)
@@ -764,10 +769,12 @@ int Pipeline::state_row_count() const { return impl_->hg.state_rows; }
 
 std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
     std::vector<PlaneView> out;
+    for (auto& g : impl_->groups) g.fresh = false;      // mutable pointers leave the pipeline: assume the planes get written
     for (size_t g = 0; g < impl_->groups.size(); ++g)
         for (int p = 0; p < 4; ++p)
             if (impl_->groups[g].mask & kPlaneBits[p])
-                out.push_back({impl_->groups[g].planes[p].data(), (int)kPlaneBits[p], (int)g});
+                out.push_back({impl_->groups[g].planes[p].data(), (int)kPlaneBits[p], (int)g,
+                               impl_->groups[g].glyph.type == GlyphType::Point ? 0 : impl_->halo});
     return out;
 }
 

@@ -145,6 +145,11 @@ void bind_engine(py::module_& m) {
                 out.append(py::make_tuple(reinterpret_cast<uintptr_t>(v.device_ptr), v.plane_kind, v.group));
             return out;
         })
+        .def("plane_reach_rows", [](const Pipeline& p) {
+            py::list out;                       // aligned with state_planes(): 0 = the plane's halo rows stay empty (Point glyph)
+            for (const auto& v : p.state_planes()) out.append(v.reach_rows);
+            return out;
+        })
         .def("tile_touched_ptr", [](const Pipeline& p) {
             int tx = 0, ty = 0;
             void* d = p.tile_touched_device(&tx, &ty);

@@ -246,7 +246,11 @@ class ShardedPipeline:
             import pcr
             rows = self.pipe.state_row_count()
             self._views = []
-            for ptr, kind, _group in self.pipe.state_planes():
+            # only planes a glyph footprint can spill from take part in the halo reduce (a Point plane's halo rows
+            # never receive anything)
+            for (ptr, kind, _group), reach in zip(self.pipe.state_planes(), self.pipe.plane_reach_rows()):
+                if reach <= 0:
+                    continue
                 view = pcr.DeviceArrayView(ptr, (rows, self.width), "<f4", owner=self.pipe)
                 self._views.append((torch.as_tensor(view, device="cuda"), kind))
             ptr, tx, ty = self.pipe.tile_touched_ptr()
@@ -304,7 +308,7 @@ class ShardedPipeline:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if self.halo > 0:
+            if self.halo > 0 and planes:
                 exchange_halos(planes, self.own, self.pipe.state_row_begin(), self.halo,
                                self.rank, self.world, blocks=self.blocks, group=self.group)
             if not self.tiles_local:
@@ -321,7 +325,7 @@ class ShardedPipeline:
         """What exchange() issues on this rank: (point-to-point halo messages, all-reduces)."""
         if self.world == 1 or self.tiles_local:
             return 0, 0
-        nplanes = len(self.pipe.state_planes())
+        nplanes = sum(1 for r in self.pipe.plane_reach_rows() if r > 0)
         neighbours = (1 if self.rank > 0 else 0) + (1 if self.rank < self.world - 1 else 0)
         return (2 * neighbours * nplanes if self.halo > 0 else 0), 1
 

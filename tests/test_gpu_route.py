@@ -156,7 +156,8 @@ def test_two_ranks_unrouted_cloud_c5_shape_matches_unsharded_oracle(tmp_path):
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
     assert parts[0]["own"].tolist() == [0, 256] and parts[1]["own"].tolist() == [256, 512]
     assert int(parts[0]["halo"]) == 4 and not bool(parts[0]["local"])          # blocks cut tiles: live exchange
-    assert parts[0]["coll"].tolist() == [4, 1] and int(parts[0]["sent"]) == 2 * 4 * G * 4   # 2 gaussian planes x 4 rows x W x 4 B
+    # only the Gaussian group's 2 planes exchange halos (send + recv each): the Point planes' halo rows stay empty
+    assert parts[0]["coll"].tolist() == [4, 1] and int(parts[0]["sent"]) == 2 * 4 * G * 4   # 2 planes x 4 rows x W x 4 B
     inb = (x >= 0) & (x <= G) & (y >= 0) & (y <= G)
     assert int(parts[0]["received"]) + int(parts[1]["received"]) == int(inb.sum())   # every valid point reached an owner, once
     for b, (rt, at) in enumerate([(1e-5, 1e-6), (1e-4, 1e-6), (0, 0)]):
