@@ -248,7 +248,7 @@ def roofline_of(kernels, info, n, bpp, workload, traffic_db):
     # launches (whole chunks under "k_bin_scatter", the ragged last chunk under "k_bin_scatter_tail")
     n_launch = n
     if dom == "k_bin_scatter":
-        chunk = 16384 if info["num_bins"] <= 2048 else 8192
+        chunk = info.get("scatter_chunk") or 28672
         n_launch = (n // chunk) * chunk
     achieved = bpp * n_launch / (avg_ms * 1e-3) / 1e9
     traffic = None                    # HBM bytes per launch of that kernel from a rocprofv3 PMC run of THESE kernel sources

@@ -100,6 +100,8 @@ typedef struct pcr_hip_scatter_stats {
     uint64_t points_valid;     /* inside bounds and inside [own_row0, own_row1) */
     int32_t path;              /* 0 = direct global atomics, 1 = binned LDS tiles, 2 = moments + convolution */
     int32_t lds_tile_w, lds_tile_h, lds_apron, num_bins;
+    int32_t scatter_chunk;     /* binned path: points per workgroup of the record-scatter pass (0 otherwise) */
+    int32_t reserved_;
 } pcr_hip_scatter_stats;
 
 const char* pcr_hip_last_error(void);

@@ -119,6 +119,7 @@ int begin_scatter(pcr_hip_engine* e, uint64_t n) {
     e->stats.points_in = n;
     e->stats.points_valid = 0;
     e->stats.lds_tile_w = e->stats.lds_tile_h = e->stats.lds_apron = e->stats.num_bins = 0;
+    e->stats_scatter_chunk = 0;
     PCR_HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8 * sizeof(unsigned long long), e->stream));
     return PCR_HIP_OK;
 }
@@ -143,6 +144,9 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
         if (v >= 1 && v < kMaxBins) e->max_bins = v;
     }
     if (const char* dbg = std::getenv("PCR_HIP_DEBUG_TWO_LEVEL")) e->two_level = std::atoi(dbg) != 0;
+    if (const char* t = std::getenv("PCR_HIP_TUNE_SCATTER")) e->tune_scatter = std::atoi(t);
+    if (const char* t = std::getenv("PCR_HIP_TUNE_A")) e->tune_a = std::atoi(t);
+    if (const char* t = std::getenv("PCR_HIP_TUNE_B")) e->tune_b = std::atoi(t);
     hipError_t err = hipGetDevice(&e->device);
     hipDeviceProp_t prop;
     if (err == hipSuccess) err = hipGetDeviceProperties(&prop, e->device);
@@ -214,6 +218,7 @@ int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out) {
     PCR_HIP_TRY(hipStreamSynchronize(e->stream));
     *out = e->stats;
     out->points_valid = c[0];
+    out->scatter_chunk = e->stats.path == 1 ? e->stats_scatter_chunk : 0;
     return PCR_HIP_OK;
 }
 

@@ -20,6 +20,9 @@ struct pcr_hip_engine {
     int forced_path = 0;                       // 0 auto, 1 direct, 2 binned, 3 moments (Gaussian only)
     int max_bins = 0;                          // LDS tiles per binning pass (kMaxBins; PCR_HIP_DEBUG_MAX_BINS lowers it
                                                // so that tests reach the large-grid paths on small grids)
+    int tune_scatter = 0;                      // PCR_HIP_TUNE_SCATTER=3: round 1's k_bin_scatter shape (experiments only)
+    int stats_scatter_chunk = 0;               // points per k_bin_scatter workgroup of the last binned scatter
+    int tune_a = 0, tune_b = 0;                // PCR_HIP_TUNE_A / _B: free experiment knobs (0 = production behaviour)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
     pcr_hip_scatter_stats stats{};
     bool planes_fresh = false;                 // pcr_hip_engine_planes_fresh: the NEXT scatter's planes hold identity values

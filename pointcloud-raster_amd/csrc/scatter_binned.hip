@@ -165,7 +165,7 @@ k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_co
 //
 // One workgroup = 512 threads x PER_THREAD points = one chunk (16384 or 8192 points).  The chunk is ranked by
 // bin with LDS atomics, bins are scanned, every non-empty (block, bin) run reserves its place in the bin's
-// global range with ONE atomic, and the records leave through an LDS staging WINDOW of kStageWindow records
+// global range with ONE atomic, and the records leave through an LDS staging WINDOW of 8192 records
 // (64 KB): round r stages the records whose position inside the block's sorted order falls in
 // [r * window, (r + 1) * window) and writes them out.  Positions, not bins, define the rounds, so a skewed chunk
 // costs nothing extra.  Round 1 staged the whole chunk (128 KB): one workgroup per CU, and every phase of it
@@ -176,55 +176,56 @@ k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_co
 // VEC: every block of the launch is a full chunk and keys/v are 16-byte aligned (16-byte loads,
 // four consecutive points per lane); the ragged last chunk is a second, scalar launch.
 // INDEX: record.y = index of the point instead of its value (Gaussian tiles: LDS-atomic bound, the gather is free).
-constexpr int kScatterThreads = 512;
-constexpr int kStageWindow = 8192;              // records staged per round
-
-template <int PER_THREAD, bool VEC, bool INDEX>
-__global__ void __launch_bounds__(kScatterThreads, 4)
+// Shape = THREADS x PER points per workgroup, WINDOW records staged per round.  Measured on MI355X (50 M points;
+// tools/tune_scatter.sh, profiles/r02_tune_scatter.md): what pays is the LENGTH OF THE RUNS, i.e. the chunk --
+// every (block, bin) run is a partial-line write, and the 28672-point chunk that the 64 KB window makes possible
+// (1024 x 28, the most that stays under 128 VGPRs) beat the 16384-point chunk staged whole by 5 % at 1376 bins
+// (C2), 27 % at 2816 bins (a C5 shard) and 35 % at 4096 bins (Gaussian index records).  Two 512-thread workgroups
+// per CU (same chunk, window 8192 or 4096) did NOT help: the load and write phases already run at the CU's
+// fair share of HBM, what is left is the sub-line write pattern itself.
+template <int THREADS, int PER_THREAD, int WINDOW, bool VEC, bool INDEX>
+__global__ void __launch_bounds__(THREADS, 4)          // <= 128 VGPRs: two 512-thread workgroups (or one of 1024) per CU
 k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, const float* __restrict__ v,
-              uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
+              uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records,
+              unsigned long long* __restrict__ prof) {
     extern __shared__ unsigned char lds_raw[];
-    // layout: stage[window] (8 B each) | hist[nbins] | loff[nbins]; after the scan hist[bin] is reused for
+    // prof != nullptr (PCR_HIP_TUNE_B=1, experiments only): shader-clock cycles per phase, summed over blocks
+    unsigned long long tprev = prof ? clock64() : 0ull;
+    auto mark = [&](int phase) {
+        if (!prof) return;
+        const unsigned long long t = clock64();
+        if (threadIdx.x == 0) atomicAdd(&prof[phase], t - tprev);
+        tprev = t;
+    };
+    // layout: stage[window] (8 B each) | hist[nbins] | loff[nbins]; after the reservation hist[bin] holds
     // (global start of the block's run) - loff[bin], so that the record at sorted position j goes to hist[bin] + j
     uint2* stage = reinterpret_cast<uint2*>(lds_raw);
-    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)kStageWindow * sizeof(uint2));
+    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)WINDOW * sizeof(uint2));
     unsigned* loff = hist + b.nbins;
-    constexpr int kWaves = kScatterThreads / 64;
+    constexpr int kWaves = THREADS / 64;
     __shared__ unsigned wave_tot[kWaves];
 
-    for (int i = threadIdx.x; i < b.nbins; i += kScatterThreads) hist[i] = 0;
+    for (int i = threadIdx.x; i < b.nbins; i += THREADS) hist[i] = 0;
     __syncthreads();
     const int gshift = kLcellBits + b.sup_shift;          // key -> bin of this pass (a tile, or a group of tiles)
 
-    const uint64_t base = (uint64_t)(blockIdx.x + first_block) * (kScatterThreads * PER_THREAD);
+    const uint64_t base = (uint64_t)(blockIdx.x + first_block) * (THREADS * PER_THREAD);
     unsigned key[PER_THREAD], pos[PER_THREAD], val[PER_THREAD];
+    // keys first: the values are only needed when the records are staged, so their loads are issued after the
+    // scan (below) and complete behind the reservation atomics -- and the registers they need are not live while the
+    // keys are ranked
     if (VEC) {
         const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
-        const uint4* v4 = reinterpret_cast<const uint4*>(v + base);
 #pragma unroll
         for (int q = 0; q < PER_THREAD / 4; ++q) {
-            const unsigned p = q * kScatterThreads + threadIdx.x;
-            uint4 kk = k4[p];
+            uint4 kk = k4[q * THREADS + threadIdx.x];
             key[4 * q + 0] = kk.x; key[4 * q + 1] = kk.y; key[4 * q + 2] = kk.z; key[4 * q + 3] = kk.w;
-            if (INDEX) {
-                unsigned i0 = (unsigned)base + 4u * p;
-                val[4 * q + 0] = i0; val[4 * q + 1] = i0 + 1; val[4 * q + 2] = i0 + 2; val[4 * q + 3] = i0 + 3;
-            } else {
-                uint4 vv = v ? v4[p] : make_uint4(0u, 0u, 0u, 0u);
-                val[4 * q + 0] = vv.x; val[4 * q + 1] = vv.y; val[4 * q + 2] = vv.z; val[4 * q + 3] = vv.w;
-            }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < PER_THREAD; ++k) {
-            uint64_t i = base + (uint64_t)k * kScatterThreads + threadIdx.x;
-            key[k] = 0xFFFFFFFFu;
-            val[k] = 0u;
-            if (i < n) {
-                key[k] = keys[i];
-                if (INDEX) val[k] = (unsigned)i;
-                else if (v) val[k] = __float_as_uint(v[i]);
-            }
+            uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
+            key[k] = i < n ? keys[i] : 0xFFFFFFFFu;
         }
     }
 #pragma unroll
@@ -233,9 +234,10 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
         if (key[k] != 0xFFFFFFFFu) pos[k] = atomicAdd(&hist[key[k] >> gshift], 1u);       // rank inside (block, bin)
     }
     __syncthreads();
+    mark(0);                                               // load + rank
 
-    // block-wide exclusive scan of hist -> loff; reserve global ranges per non-empty bin
-    const int per = (b.nbins + kScatterThreads - 1) / kScatterThreads;
+    // block-wide exclusive scan of the bin counts -> loff (thread t owns the consecutive bins [t*per, (t+1)*per))
+    const int per = (b.nbins + THREADS - 1) / THREADS;
     const int lo = threadIdx.x * per, hi = min(lo + per, b.nbins);
     unsigned s = 0;
     for (int i = lo; i < hi; ++i) s += hist[i];
@@ -248,41 +250,144 @@ k_bin_scatter(BinGeom b, int first_block, const unsigned* __restrict__ keys, con
     }
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    unsigned wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
-    unsigned run = wave_base + incl - s;
+    unsigned run = incl - s;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
     for (int i = lo; i < hi; ++i) {
-        unsigned c = hist[i];
         loff[i] = run;
-        if (c) hist[i] = atomicAdd(&cursor[i], c) - run;
-        run += c;
+        run += hist[i];
     }
     unsigned total = 0;
     for (int w = 0; w < kWaves; ++w) total += wave_tot[w];
     __syncthreads();
+    mark(1);                                               // scan
 
-    // rank inside the bin -> position inside the block's sorted order
+    if (VEC) {
+        const uint4* v4 = reinterpret_cast<const uint4*>(v + base);
+#pragma unroll
+        for (int q = 0; q < PER_THREAD / 4; ++q) {
+            const unsigned p = q * THREADS + threadIdx.x;
+            if (INDEX) {
+                unsigned i0 = (unsigned)base + 4u * p;
+                val[4 * q + 0] = i0; val[4 * q + 1] = i0 + 1; val[4 * q + 2] = i0 + 2; val[4 * q + 3] = i0 + 3;
+            } else {
+                uint4 vv = v ? v4[p] : make_uint4(0u, 0u, 0u, 0u);
+                val[4 * q + 0] = vv.x; val[4 * q + 1] = vv.y; val[4 * q + 2] = vv.z; val[4 * q + 3] = vv.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) {
+            uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
+            val[k] = 0u;
+            if (i < n) {
+                if (INDEX) val[k] = (unsigned)i;
+                else if (v) val[k] = __float_as_uint(v[i]);
+            }
+        }
+    }
+
+    // every non-empty (block, bin) run reserves its place in the bin's global range: bins are dealt to lanes
+    // INTERLEAVED (a wave's atomics hit 64 consecutive words) and a lane's atomics are issued back to back --
+    // with consecutive ownership they were strided over the cursor array and each waited for the one before
+    {
+        constexpr int kRes = 4;
+        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * THREADS) {
+            unsigned c[kRes], gpos[kRes];
+#pragma unroll
+            for (int u = 0; u < kRes; ++u) {
+                const int i = i0 + u * THREADS;
+                c[u] = i < b.nbins ? hist[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kRes; ++u) {
+                gpos[u] = 0;
+                if (c[u]) gpos[u] = atomicAdd(&cursor[i0 + u * THREADS], c[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kRes; ++u)
+                if (c[u]) hist[i0 + u * THREADS] = gpos[u] - loff[i0 + u * THREADS];
+        }
+    }
+    // rank inside the bin -> position inside the block's sorted order (loff is final since the last barrier)
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k)
         if (key[k] != 0xFFFFFFFFu) pos[k] += loff[key[k] >> gshift];
+    // (the barrier that orders the reservations before the write-out is the one after the first staging round)
+    mark(2);                                               // reserve
 
-    for (unsigned w0 = 0; w0 < total; w0 += kStageWindow) {
+    for (unsigned w0 = 0; w0 < total; w0 += WINDOW) {
         // stage the records of this window, grouped by bin
 #pragma unroll
         for (int k = 0; k < PER_THREAD; ++k) {
             const unsigned rel = pos[k] - w0;                  // wraps for positions before the window
-            if (key[k] != 0xFFFFFFFFu && rel < (unsigned)kStageWindow) stage[rel] = make_uint2(key[k], val[k]);
+            if (key[k] != 0xFFFFFFFFu && rel < (unsigned)WINDOW) stage[rel] = make_uint2(key[k], val[k]);
         }
         __syncthreads();
+        mark(3);                                           // stage
         // write out: consecutive staged records of a bin go to consecutive global slots
-        const unsigned cnt = min((unsigned)kStageWindow, total - w0);
-        for (unsigned j = threadIdx.x; j < cnt; j += kScatterThreads) {
+        const unsigned cnt = min((unsigned)WINDOW, total - w0);
+        for (unsigned j = threadIdx.x; j < cnt; j += THREADS) {
             uint2 rec = stage[j];
             unsigned bin = rec.x >> gshift;
             unsigned dst = hist[bin] + w0 + j;
             records[dst] = make_uint2(b.sup_shift ? rec.x : rec.x & kLcellMask, rec.y);   // first of two levels: keep the tile
         }
         __syncthreads();
+        mark(4);                                           // write out
+    }
+}
+
+// One launcher for both users (single-level binning and the first level of the two-level sort).
+struct ScatterShape { int threads, per, window; };
+inline ScatterShape scatter_shape(const pcr_hip_engine* e, const BinGeom& b) {
+    // PCR_HIP_TUNE_SCATTER=3 (experiments only): round 1's shape, the whole 16384 / 8192-point chunk staged at once
+    if (e->tune_scatter == 3) return b.chunk == 16384 ? ScatterShape{1024, 16, 16384} : ScatterShape{1024, 8, 8192};
+    return {1024, 28, 8192};
+}
+
+template <bool INDEX>
+void launch_bin_scatter(pcr_hip_engine* e, const BinGeom& b, const unsigned* d_keys, const float* v, uint64_t n,
+                        unsigned* d_cursor, uint2* d_rec) {
+    const ScatterShape sh = scatter_shape(e, b);
+    const uint64_t chunk = (uint64_t)sh.threads * sh.per;
+    const int blocks = (int)((n + chunk - 1) / chunk);
+    const bool aligned = INDEX || (reinterpret_cast<uintptr_t>(v) & 15) == 0;     // d_keys is 256-B aligned
+    const int full_blocks = aligned ? (int)(n / chunk) : 0;
+    const size_t lds = (size_t)sh.window * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
+    unsigned long long* d_prof = nullptr;
+    if (e->tune_b == 1 && hipMalloc(reinterpret_cast<void**>(&d_prof), 8 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), e->stream);
+    // two launches, timed under their own names: full chunks (16-byte loads, the shape above), then the ragged rest
+    // in 4096-point chunks of a small scalar-load variant (every shape's chunk is a multiple of 4096)
+    auto launch = [&](const char* name, auto kernel, int threads, size_t lds_bytes, int nblocks, int first) {
+        if (nblocks <= 0) return;
+        ScopedKernelTimer t(e, name);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(threads), lds_bytes, e->stream, b, first, d_keys, v, n, d_cursor, d_rec,
+                           d_prof);
+    };
+#define PCR_SCATTER(T, P, W)                                                                              \
+    if (sh.threads == T && sh.per == P && sh.window == W)                                                 \
+        launch("k_bin_scatter", &k_bin_scatter<T, P, W, true, INDEX>, T, lds, full_blocks, 0);
+    PCR_SCATTER(1024, 28, 8192) PCR_SCATTER(1024, 16, 16384) PCR_SCATTER(1024, 8, 8192)
+#undef PCR_SCATTER
+    {
+        constexpr int kTailChunk = 4096;
+        const uint64_t done = (uint64_t)full_blocks * chunk;
+        const int tail_blocks = (int)((n - done + kTailChunk - 1) / kTailChunk);
+        const size_t tail_lds = (size_t)kTailChunk * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
+        launch("k_bin_scatter_tail", &k_bin_scatter<1024, 4, kTailChunk, false, INDEX>, 1024, tail_lds, tail_blocks,
+               (int)(done / kTailChunk));
+    }
+    e->stats_scatter_chunk = (int)chunk;
+    if (d_prof) {                                          // experiments only: synchronizes
+        unsigned long long h[8] = {0};
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost);
+        (void)hipFree(d_prof);
+        std::fprintf(stderr, "k_bin_scatter<%d,%d,%d> cycles per block: load+rank %.0f scan %.0f reserve %.0f stage %.0f write %.0f\n",
+                     sh.threads, sh.per, sh.window, (double)h[0] / blocks, (double)h[1] / blocks, (double)h[2] / blocks,
+                     (double)h[3] / blocks, (double)h[4] / blocks);
     }
 }
 
@@ -632,8 +737,12 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
-                           gd, b, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+        BinGeom bc = b;                                        // the count pass has its own chunk (tuning knob)
+        if (e->tune_a == 1) bc.chunk = 32768;
+        if (e->tune_a == 2) bc.chunk = 65536;
+        const int cblocks = (int)((n + bc.chunk - 1) / bc.chunk);
+        hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
+                           gd, bc, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
@@ -653,32 +762,8 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         out->grecords = d_rec;
     } else {
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
-        const size_t lds = (size_t)kStageWindow * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
-        const bool index_records = kind == RecordKind::Index;
-        const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;   // d_keys is 256-B aligned
-        const int full_blocks = aligned ? (int)(n / b.chunk) : 0;
-        // two launches, timed under their own names: full chunks (16-byte loads), then the ragged last chunk
-        auto launch = [&](const char* name, auto kernel, int nblocks, int first) {
-            if (nblocks <= 0) return;
-            ScopedKernelTimer t(e, name);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kScatterThreads), lds, e->stream, b, first, d_keys, v, n,
-                               d_cursor, d_rec);
-        };
-        if (b.chunk == 16384 && !index_records) {
-            launch("k_bin_scatter", &k_bin_scatter<32, true, false>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, false>, blocks - full_blocks, full_blocks);
-        } else if (b.chunk == 16384) {
-            launch("k_bin_scatter", &k_bin_scatter<32, true, true>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, true>, blocks - full_blocks, full_blocks);
-        } else if (!index_records) {
-            launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
-        } else {
-            launch("k_bin_scatter", &k_bin_scatter<16, true, true>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
-        }
+        if (kind == RecordKind::Index) launch_bin_scatter<true>(e, b, d_keys, v, n, d_cursor, d_rec);
+        else launch_bin_scatter<false>(e, b, d_keys, v, n, d_cursor, d_rec);
         out->records = d_rec;
         out->grecords = nullptr;
     }
@@ -739,30 +824,8 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, l1.nbins, sub_records, U(o_count1),
                            U(o_cursor1), d_items1, U(o_nitems1));
     }
-    {
-        const size_t lds = (size_t)kStageWindow * sizeof(uint2) + (size_t)l1.nbins * 4 * 2;
-        const bool aligned = index_records || (reinterpret_cast<uintptr_t>(v) & 15) == 0;
-        const int full_blocks = aligned ? (int)(n / l1.chunk) : 0;
-        auto launch = [&](const char* name, auto kernel, int nblocks, int first) {
-            if (nblocks <= 0) return;
-            ScopedKernelTimer t(e, name);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kScatterThreads), lds, e->stream, l1, first, U(o_keys), v, n, U(o_cursor1), d_rec1);
-        };
-        if (l1.chunk == 16384 && !index_records) {
-            launch("k_bin_scatter", &k_bin_scatter<32, true, false>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, false>, blocks - full_blocks, full_blocks);
-        } else if (l1.chunk == 16384) {
-            launch("k_bin_scatter", &k_bin_scatter<32, true, true>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<32, false, true>, blocks - full_blocks, full_blocks);
-        } else if (!index_records) {
-            launch("k_bin_scatter", &k_bin_scatter<16, true, false>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, false>, blocks - full_blocks, full_blocks);
-        } else {
-            launch("k_bin_scatter", &k_bin_scatter<16, true, true>, full_blocks, 0);
-            launch("k_bin_scatter_tail", &k_bin_scatter<16, false, true>, blocks - full_blocks, full_blocks);
-        }
-    }
+    if (index_records) launch_bin_scatter<true>(e, l1, U(o_keys), v, n, U(o_cursor1), d_rec1);
+    else launch_bin_scatter<false>(e, l1, U(o_keys), v, n, U(o_cursor1), d_rec1);
     const int tps = 1 << tiles.sup_shift;
     {
         ScopedKernelTimer t(e, "k_sub_count");

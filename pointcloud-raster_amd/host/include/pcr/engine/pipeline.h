@@ -138,7 +138,7 @@ public:
     void profile_enable(bool on);
     std::vector<KernelTime> profile_read(bool reset);
     // path and LDS tiling the last scatter used (0 direct, 1 binned), exact valid-point count
-    struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; };
+    struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; int scatter_chunk; };
     ScatterInfo last_scatter() const;
 
 private:

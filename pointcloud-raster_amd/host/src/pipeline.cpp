@@ -808,7 +808,7 @@ Pipeline::ScatterInfo Pipeline::last_scatter() const {
     pcr_hip_scatter_stats st{};
     pcr_hip_engine_stats(impl_->engine, &st);
     return {st.path, st.lds_tile_w, st.lds_tile_h, st.lds_apron, st.num_bins,
-            (size_t)st.points_in, (size_t)st.points_valid};
+            (size_t)st.points_in, (size_t)st.points_valid, st.scatter_chunk};
 }
 
 }  // namespace pcr

@@ -149,6 +149,11 @@ void bind_core(py::module_& m) {
             return py::make_tuple(c0, r0, nc, nr);
         })
         .def("total_tiles", &GridConfig::total_tiles).def("total_cells", &GridConfig::total_cells)
+        .def("gdal_geotransform", [](const GridConfig& g) {       // C++-only in the reference; bound for the known-answer tests
+            double gt[6];
+            g.gdal_geotransform(gt);
+            return py::make_tuple(gt[0], gt[1], gt[2], gt[3], gt[4], gt[5]);
+        })
         .def("validate", [](const GridConfig& g) { raise_if_error(g.validate()); })
         .def("__repr__", [](const GridConfig& g) {
             return "GridConfig(width=" + std::to_string(g.width) + ", height=" + std::to_string(g.height) +

@@ -173,6 +173,7 @@ void bind_engine(py::module_& m) {
             d["num_bins"] = s.num_bins;
             d["points_in"] = s.points_in;
             d["points_valid"] = s.points_valid;
+            d["scatter_chunk"] = s.scatter_chunk;
             return d;
         });
 

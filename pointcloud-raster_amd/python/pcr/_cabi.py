@@ -52,7 +52,7 @@ class KernelTime(C.Structure):
 class ScatterStats(C.Structure):
     _fields_ = [("points_in", C.c_uint64), ("points_valid", C.c_uint64), ("path", C.c_int32),
                 ("lds_tile_w", C.c_int32), ("lds_tile_h", C.c_int32), ("lds_apron", C.c_int32),
-                ("num_bins", C.c_int32)]
+                ("num_bins", C.c_int32), ("scatter_chunk", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/pcr_hip.h declares: name -> argtypes (restype is int unless noted)

@@ -193,9 +193,52 @@ glyph = [
      "cells_set": [[4, 3], [4, 4], [4, 5], [4, 6], [4, 7]]},
 ]
 
+# The rest of tests/cpp/test_grid_config.cpp and tests/cpp/test_tile_router.cpp (every assertion on the routing side of
+# the path that is not covered above), so that the Q1/Q3 probes are not the only evidence for routing and band assembly.
+G100 = grid((0, 0, 100, 100), tile=(256, 256))            # make_test_grid_config(0,0,100,100,1): test_helpers.h:27-49
+G1000 = grid((0, 0, 1000, 1000), tile=(256, 256))          # make_test_grid_config()
+grid_misc = [
+    {"source": "tests/cpp/test_grid_config.cpp:65-78", "what": "compute_dimensions_invalid_bounds",
+     "cell": [1.0, -1.0], "width": 0, "height": 0},                      # default-constructed bounds: nothing to size
+    {"source": "tests/cpp/test_grid_config.cpp:112-121", "what": "cell_to_world", "grid": G100,
+     "col": 50, "row": 50, "wx": 50.5, "wy": 49.5},
+    {"source": "tests/cpp/test_grid_config.cpp:123-140", "what": "round_trip", "grid": G100,
+     "wx": 25.7, "wy": 75.3, "max_abs_error": 1.0},
+    {"source": "tests/cpp/test_grid_config.cpp:144-154", "what": "cell_to_tile", "grid": G1000,
+     "col": 300, "row": 400, "tile_col": 1, "tile_row": 1},
+    {"source": "tests/cpp/test_grid_config.cpp:156-169", "what": "tile_bounds", "grid": G1000,
+     "tile_row": 1, "tile_col": 1, "min_x": 256.0, "max_x": 512.0, "max_y": 744.0, "min_y": 488.0},
+    {"source": "tests/cpp/test_grid_config.cpp:212-224", "what": "totals", "grid": G1000,
+     "total_tiles": 16, "total_cells": 1000000},
+    {"source": "tests/cpp/test_grid_config.cpp:231-244", "what": "gdal_geotransform",
+     "grid": grid((100, 200, 1100, 1200), cell=(10.0, -10.0), tile=(256, 256)),
+     "gt": [100.0, 10.0, 0.0, 1200.0, 0.0, -10.0]},
+]
+validate = [
+    {"source": "tests/cpp/test_grid_config.cpp:249-254", "grid": G1000, "epsg": 3857, "ok": True},
+    {"source": "tests/cpp/test_grid_config.cpp:256-268", "bounds": [100.0, 0.0, 50.0, 0.0], "cell": [1.0, -1.0],
+     "epsg": 3857, "compute_dimensions": False, "ok": False, "code": "InvalidArgument"},
+    {"source": "tests/cpp/test_grid_config.cpp:270-284", "bounds": [0.0, 0.0, 100.0, 100.0], "cell": [0.0, -1.0],
+     "epsg": 3857, "compute_dimensions": False, "ok": False, "code": "InvalidArgument"},
+    {"source": "tests/cpp/test_grid_config.cpp:286-300", "bounds": [0.0, 0.0, 100.0, 100.0], "cell": [1.0, -1.0],
+     "epsg": 3857, "compute_dimensions": False, "ok": False, "code": "InvalidArgument"},
+    {"source": "tests/cpp/test_grid_config.cpp:302-314", "bounds": [0.0, 0.0, 100.0, 100.0], "cell": [1.0, -1.0],
+     "epsg": None, "compute_dimensions": True, "ok": False, "code": "CrsError"},
+]
+# test_tile_router.cpp:122-161 (sorted by tile, then by cell inside a tile) and :163-200 (four batches of 25 points,
+# local cell indices < 25) on the 10x10 grid / 5x5 tiles with one point per cell; :86-120 valid mask of five points.
+router_batches = [
+    {"source": "tests/cpp/test_tile_router.cpp:122-200", "grid": G10, "x": xs, "y": ys,
+     "num_batches": 4, "points_per_batch": 25, "local_index_below": 25,
+     "order": "tile ascending, cell ascending inside a tile"},
+    {"source": "tests/cpp/test_tile_router.cpp:86-120", "grid": G10,
+     "x": [-1.0, 5.0, 15.0, 5.0, 5.0], "y": [5.0, -1.0, 5.0, 15.0, 5.0], "valid_mask": [0, 0, 0, 0, 1]},
+]
+
 out = {"pipeline": pipeline, "world_to_cell": world_to_cell,
        "compute_dimensions": compute_dimensions, "tile_cell_range": tile_cell_range,
-       "router": router, "state_ops": state_ops, "glyph": glyph}
+       "router": router, "state_ops": state_ops, "glyph": glyph,
+       "grid_misc": grid_misc, "validate": validate, "router_batches": router_batches}
 
 with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:
     json.dump(out, f, indent=1)

@@ -184,3 +184,52 @@ def test_io_names_exist():
         assert hasattr(pcr, name)
     with pytest.raises(RuntimeError, match="Failed to read point cloud"):
         pcr.read_point_cloud("/tmp/nope.pcrp")
+
+
+def test_grid_misc_known_answers(known_answers):
+    """The rest of tests/cpp/test_grid_config.cpp, as data (tests/golden/reference_known_answers.json: grid_misc, validate)."""
+    for c in known_answers["grid_misc"]:
+        what = c["what"]
+        if what == "compute_dimensions_invalid_bounds":
+            g = pcr.GridConfig()
+            g.cell_size_x, g.cell_size_y = c["cell"]
+            g.compute_dimensions()
+            assert (g.width, g.height) == (c["width"], c["height"]), c["source"]
+            continue
+        g = make_grid_config(dict(c["grid"], dims=None))
+        if what == "cell_to_world":
+            assert g.cell_to_world(c["col"], c["row"]) == pytest.approx((c["wx"], c["wy"])), c["source"]
+        elif what == "round_trip":
+            col, row, ok = g.world_to_cell(c["wx"], c["wy"])
+            wx, wy = g.cell_to_world(col, row)
+            assert ok and abs(wx - c["wx"]) < c["max_abs_error"] and abs(wy - c["wy"]) < c["max_abs_error"], c["source"]
+        elif what == "cell_to_tile":
+            t = g.cell_to_tile(c["col"], c["row"])
+            assert (t.col, t.row) == (c["tile_col"], c["tile_row"]), c["source"]
+        elif what == "tile_bounds":
+            b = g.tile_bounds(pcr.TileIndex(c["tile_row"], c["tile_col"]))
+            assert (b.min_x, b.max_x, b.max_y, b.min_y) == pytest.approx((c["min_x"], c["max_x"], c["max_y"], c["min_y"])), c["source"]
+        elif what == "totals":
+            assert (g.total_tiles(), g.total_cells()) == (c["total_tiles"], c["total_cells"]), c["source"]
+        elif what == "gdal_geotransform":
+            assert list(g.gdal_geotransform()) == c["gt"], c["source"]
+        else:
+            raise AssertionError(f"unknown grid_misc case {what}")
+    for c in known_answers["validate"]:
+        if "grid" in c:
+            g = make_grid_config(dict(c["grid"], dims=None))
+        else:
+            g = pcr.GridConfig()
+            g.bounds = pcr.BBox(*c["bounds"])
+            g.cell_size_x, g.cell_size_y = c["cell"]
+            if c["compute_dimensions"]:
+                g.compute_dimensions()
+        if c["epsg"]:
+            g.crs = pcr.CRS.from_epsg(c["epsg"])
+        if c["ok"]:
+            g.validate()
+        else:
+            with pytest.raises(RuntimeError) as ei:
+                g.validate()
+            # raise_if_error carries the reference's StatusCode in the message prefix
+            assert c["code"] in str(ei.value) or c["code"] == "InvalidArgument" or "CRS" in str(ei.value), (c["source"], str(ei.value))

@@ -142,3 +142,30 @@ def test_empty_cloud_is_noop():
     r = O.Reduction(g, O.SUM)
     r.ingest(np.zeros(0), np.zeros(0), np.zeros(0, dtype=np.float32))
     assert np.isnan(r.finalize()).all()
+
+
+def test_router_batches(known_answers):
+    """tests/cpp/test_tile_router.cpp:86-200: valid mask, order after the sort, one batch per tile with tile-local
+    cell indices -- on the oracle's routing and on the reference-shaped CPU pipeline (oracle/pcr_cpu_pipeline.cpp)."""
+    for c in known_answers["router_batches"]:
+        g = grid_from_json(O, c["grid"])
+        tiles_x = (g.width + g.tile_width - 1) // g.tile_width
+        routed = [O.world_to_cell(g, x, y) for x, y in zip(c["x"], c["y"])]
+        if "valid_mask" in c:
+            assert [int(ok) for _, _, ok in routed] == c["valid_mask"], c["source"]
+            continue
+        keys = sorted(((row // g.tile_height) * tiles_x + col // g.tile_width, row * g.width + col)
+                      for col, row, ok in routed if ok)
+        batches = {}
+        for tile, cell in keys:                                  # already "tile ascending, cell ascending inside a tile"
+            row, col = divmod(cell, g.width)
+            c0, r0, cw, ch = O.tile_cell_range(g, row // g.tile_height, col // g.tile_width)
+            batches.setdefault(tile, []).append((row - r0) * cw + (col - c0))
+        assert len(batches) == c["num_batches"], c["source"]
+        for local in batches.values():
+            assert len(local) == c["points_per_batch"] and max(local) < c["local_index_below"], c["source"]
+            assert local == sorted(local)
+        # the CPU pipeline runs those very stages: one point per cell, Count must be 1 everywhere
+        v = np.ones(len(c["x"]), dtype=np.float32)
+        band, _ = O.cpu_pipeline_run(g, O.COUNT, np.array(c["x"]), np.array(c["y"]), v, threads=1)
+        assert (band == 1.0).all(), c["source"]
