@@ -242,6 +242,12 @@ int pcr_hip_engine_profile_enable(pcr_hip_engine* e, int on) {
     return PCR_HIP_OK;
 }
 
+int pcr_hip_engine_profile_only(pcr_hip_engine* e, const char* kernel_name) {
+    PCR_REQUIRE(e, "engine_profile_only: null engine");
+    e->profile_only = kernel_name ? kernel_name : "";
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_engine_profile_read(pcr_hip_engine* e, pcr_hip_kernel_time* out, int capacity, int* count, int reset) {
     PCR_REQUIRE(e && count, "engine_profile_read: null argument");
     DeviceGuard dev(e->device);

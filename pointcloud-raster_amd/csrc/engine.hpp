@@ -29,6 +29,7 @@ struct pcr_hip_engine {
 
     // optional per-kernel event timing
     bool profiling = false;
+    std::string profile_only;                  // non-empty: only launches timed under this name are bracketed by events
     struct Pending { const char* name; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::map<std::string, std::pair<uint32_t, double>> kernel_ms;
@@ -58,6 +59,7 @@ struct ScopedKernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     ScopedKernelTimer(pcr_hip_engine* eng, const char* nm) : e(eng), name(nm) {
         if (!e->profiling) return;
+        if (!e->profile_only.empty() && e->profile_only != nm) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, e->stream);
     }

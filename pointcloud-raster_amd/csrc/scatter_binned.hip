@@ -465,10 +465,13 @@ k_sub_scatter(int sup_shift, const uint2* __restrict__ rec, const BinItem* __res
     unsigned run = incl - s;
     for (int w = 0; w < wave; ++w) run += wave_tot[w];
     for (int i = lo; i < hi; ++i) {
-        const unsigned c = hist[i];
         loff[i] = run;
+        run += hist[i];
+    }
+    // reservations: tiles dealt to lanes interleaved (coalesced atomics)
+    for (int i = threadIdx.x; i < tps; i += kThreads) {
+        const unsigned c = hist[i];
         if (c) gbase[i] = atomicAdd(&cursor[tile0 + i], c);
-        run += c;
     }
     __syncthreads();
 #pragma unroll
@@ -516,9 +519,24 @@ k_rec_scatter(BinGeom b, GlyphDev gl, const unsigned* __restrict__ keys, const d
         if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) {
-        const unsigned c = hist[i];
-        if (c) hist[i] = atomicAdd(&cursor[i], c);          // now: where this block's run of bin i starts
+    {
+        constexpr int kRes = 4;                               // a lane's reservations are issued back to back
+        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * kThreads) {
+            unsigned c[kRes], gp[kRes];
+#pragma unroll
+            for (int u = 0; u < kRes; ++u) {
+                const int i = i0 + u * kThreads;
+                c[u] = i < b.nbins ? hist[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kRes; ++u) {
+                gp[u] = 0;
+                if (c[u]) gp[u] = atomicAdd(&cursor[i0 + u * kThreads], c[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kRes; ++u)
+                if (c[u]) hist[i0 + u * kThreads] = gp[u];  // now: where this block's run of the bin starts
+        }
     }
     __syncthreads();
 #pragma unroll

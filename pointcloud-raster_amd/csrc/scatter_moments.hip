@@ -218,14 +218,32 @@ k_mom_scatter(GridDev g, BinGeom b, const unsigned* __restrict__ keys, const dou
     for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
     unsigned run = wave_base + incl - s;
     for (int i = lo; i < hi; ++i) {
-        unsigned c = hist[i];
         loff[i] = run;
-        if (c) gbase[i] = atomicAdd(&cursor[i], c);
-        run += c;
+        run += hist[i];
     }
     unsigned total = 0;
     for (int w = 0; w < kThreads / 64; ++w) total += wave_tot[w];
     __syncthreads();
+    // reservations: bins dealt to lanes interleaved (a wave's atomics hit 64 consecutive words), issued back to back
+    {
+        constexpr int kRes = 4;
+        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * kThreads) {
+            unsigned c[kRes], gp[kRes];
+#pragma unroll
+            for (int u = 0; u < kRes; ++u) {
+                const int i = i0 + u * kThreads;
+                c[u] = i < b.nbins ? hist[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kRes; ++u) {
+                gp[u] = 0;
+                if (c[u]) gp[u] = atomicAdd(&cursor[i0 + u * kThreads], c[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kRes; ++u)
+                if (c[u]) gbase[i0 + u * kThreads] = gp[u];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < kScatterPer; ++k)
         if (key[k] != 0xFFFFFFFFu)

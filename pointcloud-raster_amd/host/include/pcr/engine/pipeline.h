@@ -135,7 +135,7 @@ public:
     void* stream_handle() const;                 // the hipStream_t every kernel of this pipeline runs on (may be null)
     // per-kernel HIP-event timing of the scatter kernels (roofline reporting)
     struct KernelTime { std::string name; unsigned launches; double total_ms; };
-    void profile_enable(bool on);
+    void profile_enable(bool on, const std::string& only_kernel = "");   // only_kernel: bracket just that kernel with events
     std::vector<KernelTime> profile_read(bool reset);
     // path and LDS tiling the last scatter used (0 direct, 1 binned), exact valid-point count
     struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; int scatter_chunk; };

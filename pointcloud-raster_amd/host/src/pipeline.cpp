@@ -793,7 +793,10 @@ Status Pipeline::load_state(const std::string& dir) { return impl_->load_state(d
 Status Pipeline::synchronize() { return detail::hip_status(pcr_hip_stream_synchronize(impl_->stream)); }
 void* Pipeline::stream_handle() const { return impl_->stream; }
 
-void Pipeline::profile_enable(bool on) { pcr_hip_engine_profile_enable(impl_->engine, on ? 1 : 0); }
+void Pipeline::profile_enable(bool on, const std::string& only_kernel) {
+    pcr_hip_engine_profile_only(impl_->engine, only_kernel.c_str());
+    pcr_hip_engine_profile_enable(impl_->engine, on ? 1 : 0);
+}
 
 std::vector<Pipeline::KernelTime> Pipeline::profile_read(bool reset) {
     std::vector<KernelTime> out;

@@ -157,7 +157,7 @@ void bind_engine(py::module_& m) {
         })
         .def("synchronize", [](Pipeline& p) { raise_if_error(p.synchronize()); })
         .def("stream_ptr", [](const Pipeline& p) { return reinterpret_cast<uintptr_t>(p.stream_handle()); })
-        .def("profile_enable", &Pipeline::profile_enable)
+        .def("profile_enable", &Pipeline::profile_enable, py::arg("on"), py::arg("only_kernel") = "")
         .def("profile_read", [](Pipeline& p, bool reset) {
             py::dict d;
             for (const auto& k : p.profile_read(reset))

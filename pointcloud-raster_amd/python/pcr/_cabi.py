@@ -106,6 +106,7 @@ SYMBOLS = {
     "pcr_hip_filter_mask": [C.POINTER(Predicate), C.c_int, _U64, _VP, _VP, _VP],
     "pcr_hip_engine_set_point_mask": [_VP, _VP],
     "pcr_hip_engine_profile_enable": [_VP, C.c_int],
+    "pcr_hip_engine_profile_only": [_VP, C.c_char_p],
     "pcr_hip_engine_profile_read": [_VP, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int), C.c_int],
     "pcr_hip_scatter_point": [_VP, _U32, C.POINTER(Planes), _VP, _VP, _VP, _U64],
     "pcr_hip_scatter_glyph": [_VP, C.POINTER(Glyph), _U32, C.POINTER(Planes), _VP, _VP, _VP, _U64],
