@@ -224,10 +224,11 @@ def time_steps(pipes, cloud, warmup, world, backend):
                 k[1] += ms
         return kernels
 
+    warm = {}
     for sp in pipes[:warmup]:
         sp.pipe.profile_enable(True)
         step(sp)
-    warm = drain(pipes[:warmup])
+        warm = drain([sp])                        # the LAST warm-up step's table (the first one is cold)
     dom = max(warm, key=lambda k: warm[k][1]) if warm else ""
     on = os.environ.get("PCR_BENCH_NO_PROFILE") != "1"
     for sp in pipes[warmup:]:
@@ -256,12 +257,7 @@ def roofline_of(kernels, info, n, bpp, workload, traffic_db):
     dom = max(kernels, key=lambda k: kernels[k][1])
     launches, ms = kernels[dom]
     avg_ms = ms / launches
-    # points one launch of that kernel processes: all of the ingest, except that the binning scatter is two
-    # launches (whole chunks under "k_bin_scatter", the ragged last chunk under "k_bin_scatter_tail")
-    n_launch = n
-    if dom == "k_bin_scatter":
-        chunk = info.get("scatter_chunk") or 28672
-        n_launch = (n // chunk) * chunk
+    n_launch = n                      # one launch of any binned-path kernel processes all N points of the ingest
     achieved = bpp * n_launch / (avg_ms * 1e-3) / 1e9
     traffic = None                    # HBM bytes per launch of that kernel from a rocprofv3 PMC run of THESE kernel sources
     pmc = traffic_db.get(workload, {})
@@ -374,7 +370,7 @@ def main():
             dist.barrier()
             sp.exchange(timed=True)
             extra["exchange_ms"] = round(sp.exchange_ms, 4)
-        extra["_warm"] = {k: round(v[1] / max(warmup, 1), 4) for k, v in sorted(warm.items())}
+        extra["_warm"] = {k: round(v[1], 4) for k, v in sorted(warm.items())}
         del pipes
         return elapsed, kernels, info, cfg, extra
 
@@ -415,7 +411,7 @@ def main():
         roof, dom = roofline_of(kernels, info, n, bpp, workload, traffic_db)
         if roof:
             out["roofline"] = roof
-            out["kernels_ms_per_step"] = dict(warm_table, _note="warm-up steps, every kernel bracketed by HIP events (which cost "
+            out["kernels_ms_per_step"] = dict(warm_table, _note="last warm-up step, every kernel bracketed by HIP events (which cost "
                                               "the stream ~4 us each); the timed steps bracket the dominant kernel only")
             # the whole step against the same roof: algorithmic bytes in + finalized bands out
             step_bytes = bpp * n + 4 * G * (r1 - r0) * len(cfg.reductions)
@@ -425,7 +421,7 @@ def main():
 
     # ---- the rest of the metric, same run ---------------------------------------------------------
     if not args.no_extras and args.workload is None and not args.host_cloud and not args.host_result:
-        k_extra, w_extra = max(3, min(args.steps, 5)), 1
+        k_extra, w_extra = max(3, min(args.steps, 5)), 2
         per_glyph = {}
         for wl in (PER_GLYPH if world == 1 else (("C5_gauss1",) if strong else ())):
             try:

@@ -180,7 +180,10 @@ typedef struct pcr_hip_engine pcr_hip_engine;
 /* scratch_bytes = 0: the engine grows its scratch arena on demand (the arena is shared by all engines of a device).
  * Test-only environment knobs, read here: PCR_HIP_DEBUG_MAX_BINS=<n> lowers the number of LDS tiles one binning pass
  * may count (8064) so that the large-grid paths (two-level sort, row bands) are reached on small grids;
- * PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep where the two-level sort would apply. */
+ * PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep where the two-level sort would apply.
+ * Opt-in: PCR_HIP_ONE_PASS=1 selects the one-pass (sampled provisioning) sort for Point-glyph scatters of >= 2^18 points
+ * on one window of <= 4096 LDS tiles: 23 % less HBM traffic, same time (csrc/scatter_binned.hip, k_bin_scatter1);
+ * PCR_HIP_DEBUG_PROVISION=<0..100> starves its bin provisions so that tests reach its overflow path. */
 int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s);
 int pcr_hip_engine_destroy(pcr_hip_engine* e);
 /* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot

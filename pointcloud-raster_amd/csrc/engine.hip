@@ -144,8 +144,8 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
         if (v >= 1 && v < kMaxBins) e->max_bins = v;
     }
     if (const char* dbg = std::getenv("PCR_HIP_DEBUG_TWO_LEVEL")) e->two_level = std::atoi(dbg) != 0;
+    if (const char* t = std::getenv("PCR_HIP_ONE_PASS")) e->one_pass = std::atoi(t) != 0;
     if (const char* t = std::getenv("PCR_HIP_TUNE_SCATTER")) e->tune_scatter = std::atoi(t);
-    if (const char* t = std::getenv("PCR_HIP_TUNE_A")) e->tune_a = std::atoi(t);
     if (const char* t = std::getenv("PCR_HIP_TUNE_B")) e->tune_b = std::atoi(t);
     hipError_t err = hipGetDevice(&e->device);
     hipDeviceProp_t prop;

@@ -22,7 +22,8 @@ struct pcr_hip_engine {
                                                // so that tests reach the large-grid paths on small grids)
     int tune_scatter = 0;                      // PCR_HIP_TUNE_SCATTER=3: round 1's k_bin_scatter shape (experiments only)
     int stats_scatter_chunk = 0;               // points per k_bin_scatter workgroup of the last binned scatter
-    int tune_a = 0, tune_b = 0;                // PCR_HIP_TUNE_A / _B: free experiment knobs (0 = production behaviour)
+    int tune_b = 0;                            // PCR_HIP_TUNE_B=1: print k_bin_scatter's phase cycles (experiments only; synchronizes)
+    bool one_pass = false;                     // PCR_HIP_ONE_PASS=1: sampled-provisioning one-pass sort for the Point glyph (opt-in)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
     pcr_hip_scatter_stats stats{};
     bool planes_fresh = false;                 // pcr_hip_engine_planes_fresh: the NEXT scatter's planes hold identity values

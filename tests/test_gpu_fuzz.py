@@ -110,7 +110,12 @@ def test_random_case_matches_oracle(A, seed):
     assert st.points_valid == ref.points_valid(), what
     exact = O.run(og, rt, c["x"], c["y"], c["v"], glyph=c["ogl"], wide=True, **c["ch"]).astype(np.float64)
     gn, wn = np.isnan(got), np.isnan(want)
-    if c["kind"].startswith("gauss"):
+    if c["kind"].startswith("gauss") and st.path == 2:
+        # moment path: it is only taken when the reference's 1e-6 weight cut-off is provably dead inside the window
+        # (make_plan, scatter_moments.hip), so there is no cell whose inclusion hangs on an ulp: the mask is exact
+        assert np.array_equal(gn, wn), f"{what}: NaN mask (moment path)"
+    elif c["kind"].startswith("gauss"):
+        # splat paths: a cell whose only contributions sit within an ulp of the 1e-6 cut-off may flip
         assert (gn != wn).sum() <= max(2, int(1e-4 * gn.size)), f"{what}: NaN mask"
     else:
         assert np.array_equal(gn, wn), f"{what}: NaN mask"
