@@ -302,4 +302,32 @@ __device__ __forceinline__ void line_walk(const LineParams& q, Sink& sink) {
     }
 }
 
+// The same walk for a whole WAVE of segments at once (tile kernels): every lane visits exactly max(ddx, ddy) + 1 cells
+// (a Bresenham segment advances along its major axis every step), so the loop runs to the longest segment of the wave
+// with lanes masked off as they finish, and the two error updates are selects.  The per-lane form above spends more
+// scalar instructions on its three data-dependent branches per step than vector instructions on the walk
+// (rocprofv3: 617 SALU vs 1077 VALU wave-instructions per 64 segments in k_tile_line).
+template <typename Sink>
+__device__ __forceinline__ void line_walk_wave(const LineParams& q, bool valid, Sink& sink) {
+    int ddx = abs(q.ix1 - q.ix0), ddy = abs(q.iy1 - q.iy0);
+    const int sxs = q.ix0 < q.ix1 ? 1 : -1, sys = q.iy0 < q.iy1 ? 1 : -1;
+    int err = ddx - ddy, cx = q.ix0, cy = q.iy0;
+    const long long bound = 2ll * ((long long)ddx + ddy) + 2;
+    if (!valid || bound > (1ll << 24)) { ddx = ddy = -1; }              // nothing to visit (garbage segments are dropped)
+    int left = max(ddx, ddy) + 1;                                       // cells this lane still has to visit
+    int longest = left;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
+    for (int step = 0; step < longest; ++step) {
+        const bool on = left > 0;
+        if (on && cx >= q.cx0 && cx < q.cx1 && cy >= q.cy0 && cy < q.cy1) sink.add(cy, cx, q.val, 1.0f);
+        --left;
+        const int e2 = 2 * err;
+        const bool mx = e2 > -ddy, my = e2 < ddx;
+        err += (mx ? -ddy : 0) + (my ? ddx : 0);
+        cx += mx ? sxs : 0;
+        cy += my ? sys : 0;
+    }
+}
+
 }  // namespace pcrhip

@@ -54,13 +54,17 @@ struct MomPlan {
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u; }
 
 // ---- pass A: eligibility + histogram -----------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads)
+// 512-thread workgroups, like k_bin_count: the kernel is SGPR-limited to 7 waves per SIMD, so 1024-thread groups ran one
+// per CU; three groups of 512 keep half as many loads again in flight.
+constexpr int kMomCountThreads = 512;
+
+__global__ void __launch_bounds__(kMomCountThreads)
 k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
             const float* __restrict__ v, uint64_t n, unsigned* __restrict__ keys,
             unsigned* __restrict__ bin_count, unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count,
             uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
     extern __shared__ unsigned lds_hist[];
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) lds_hist[i] = 0;
+    for (int i = threadIdx.x; i < b.nbins; i += kMomCountThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
@@ -73,7 +77,7 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         touch_tile(g, touched, pg.row, pg.col);
         int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);
         if (finite_f(val) && icx == pg.col && icy == pg.row) {
-            int sr = pg.row - g.st_r0;
+            int sr = pg.row - g.st_r0 - b.row0;                    // row inside the band the bins cover
             int bx = fast_div(pg.col, b.tile_w), by = fast_div(sr, b.tile_h);
             int bin = by * b.bins_x + bx;
             atomicAdd(&lds_hist[bin], 1u);
@@ -92,27 +96,27 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         const float2* v2 = reinterpret_cast<const float2*>(v + base);
         uint2* k2 = reinterpret_cast<uint2*>(keys + base);
         const int pairs = b.chunk >> 1;                          // 4096 or 2048 pairs: one trip, 4 or 2 loads per array
-        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kThreads) {
+        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kMomCountThreads) {
             double2 xs[4], ys[4];
             float2 vs[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (p0 + u * kThreads >= pairs) break;           // uniform
-                xs[u] = x2[p0 + u * kThreads];
-                ys[u] = y2[p0 + u * kThreads];
-                vs[u] = v2[p0 + u * kThreads];
+                if (p0 + u * kMomCountThreads >= pairs) break;           // uniform
+                xs[u] = x2[p0 + u * kMomCountThreads];
+                ys[u] = y2[p0 + u * kMomCountThreads];
+                vs[u] = v2[p0 + u * kMomCountThreads];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (p0 + u * kThreads >= pairs) break;
-                const uint64_t i = base + 2ull * (p0 + u * kThreads);
+                if (p0 + u * kMomCountThreads >= pairs) break;
+                const uint64_t i = base + 2ull * (p0 + u * kMomCountThreads);
                 unsigned ka = handle(i, xs[u].x, ys[u].x, vs[u].x);
                 unsigned kb = handle(i + 1, xs[u].y, ys[u].y, vs[u].y);
-                k2[p0 + u * kThreads] = make_uint2(ka, kb);
+                k2[p0 + u * kMomCountThreads] = make_uint2(ka, kb);
             }
         }
     } else {
-        for (int k = threadIdx.x; k < b.chunk; k += kThreads) {
+        for (int k = threadIdx.x; k < b.chunk; k += kMomCountThreads) {
             uint64_t i = base + k;
             if (i >= n) break;
             keys[i] = handle(i, x[i], y[i], v[i]);
@@ -120,7 +124,7 @@ k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
     __syncthreads();
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) {
+    for (int i = threadIdx.x; i < b.nbins; i += kMomCountThreads) {
         unsigned c = lds_hist[i];
         if (c) atomicAdd(&bin_count[i], c);
     }
@@ -992,7 +996,7 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));
         {
             ScopedKernelTimer t(e, "k_mom_count");
-            hipLaunchKernelGGL(k_mom_count, dim3(blocks), dim3(kThreads), (size_t)b.nbins * 4, e->stream, g, b, x, y, v, n,
+            hipLaunchKernelGGL(k_mom_count, dim3(blocks), dim3(kMomCountThreads), (size_t)b.nbins * 4, e->stream, g, b, x, y, v, n,
                                d_keys, d_count, d_fbl, d_fbc, e->d_touched, e->d_counters);
         }
         {
