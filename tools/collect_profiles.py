@@ -24,11 +24,19 @@ def kname(full):
 
 
 def pmc_means(path):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    """{kernel base name: {counter: [per-launch values]}}; template variants of one kernel (e.g. a full-chunk and a
+    ragged-end launch) are kept apart and the variant with the larger mean represents the name."""
+    per_variant = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return agg
+            per_variant[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    agg = {}
+    for full, d in per_variant.items():
+        base = kname(full)
+        size = max(sum(v) / len(v) for v in d.values())
+        if base not in agg or size > agg[base][0]:
+            agg[base] = (size, d)
+    return {k: v[1] for k, v in agg.items()}
 
 
 def main():
