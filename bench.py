@@ -21,8 +21,10 @@ points in total, row blocks from pcr.distributed.row_block (2048 rows at N = 8: 
 reference tiles, so the touched-tile union and -- for Gaussians -- the halo rows really cross RCCL).  Every
 rank generates, on its device, the 1e9/N points of the cloud that fall in its block (seed 42 + rank): points
 arrive routed by y.  `value` = Point / Average; `per_glyph.gauss1` = Gaussian sigma = 1 (r <= 4) / Average in
-the same run.  --unrouted adds `unrouted`: the same Point step when each rank is instead handed an ARBITRARY
-1/N of the cloud and the step includes the device-side partition + all-to-all (pcr.distributed.route_cloud).
+the same run; `one_gpu_same_problem` = the same 1 B points on rank 0's GPU alone (the other ranks wait), so that the line
+carries its own denominator (`speedup_vs_one_gpu`).  --unrouted adds `unrouted`: the same Point step when each rank is
+instead handed an ARBITRARY 1/N of the cloud and the step includes the device-side partition + all-to-all
+(pcr.distributed.route_cloud).
 --weak keeps round 1's shape (4096 x 4096*N grid, 50 M points per GPU, tile-aligned blocks, no collective).
 """
 import argparse
@@ -489,6 +491,39 @@ def main():
             except Exception as exc:
                 if rank == 0:
                     out["unrouted"] = {"error": repr(exc)}
+
+    if strong and not args.no_extras and args.workload is None:
+        # the SAME problem on ONE GPU (rank 0 alone, the other ranks wait): the denominator of "x-fold at N GPUs on the
+        # 16384^2 grid".  The driver's own N = 1 run measures C2 (4096^2), which is a different problem.
+        one = None
+        if rank == 0:
+            try:
+                del cloud
+                total_pts = n * world
+                whole = device_cloud_uniform(total_pts, 2.0, G - 2.0, 2.0, H - 2.0, seed=42)
+                cfg1 = make_cfg(workload)
+                cfg1.gpu_pool_size_bytes = 24 * total_pts + (64 << 20)
+                pipes = [pcr.Pipeline.create(cfg1) for _ in range(3)]
+                if any(p is None for p in pipes):
+                    raise RuntimeError(pcr.pipeline_create_error())
+                pipes[0].ingest(whole)
+                pipes[0].finalize()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for p in pipes[1:]:
+                    p.ingest(whole)
+                    p.finalize()
+                torch.cuda.synchronize()
+                ms1 = (time.perf_counter() - t0) / 2 * 1e3
+                one = {"ms_per_step": round(ms1, 3), "Mpts/s": round(total_pts / ms1 / 1e3, 2), "steps": 2,
+                       "what": f"{workload} with all {total_pts} points on rank 0's GPU alone (same grid, unsharded pipeline)"}
+                del pipes, whole
+            except Exception as exc:
+                one = {"error": repr(exc)}
+            out["one_gpu_same_problem"] = one
+            if "Mpts/s" in one:
+                out["speedup_vs_one_gpu"] = round(out["value"] / one["Mpts/s"], 3)
+        dist.barrier()
 
     if rank == 0:
         sample = args.cpu_sample

@@ -42,6 +42,7 @@ def test_default_multi_gpu_bench_is_c5_strong_scaling_with_live_exchange():
     assert g1["exchange"]["halo_bytes_sent_per_step"] == 2 * 4 * 6144 * 4
     assert g1["Mpts/s"] > 0 and r["value"] > 0
     assert r["unrouted"]["Mpts/s"] > 0
+    assert r["one_gpu_same_problem"]["Mpts/s"] > 0 and r["speedup_vs_one_gpu"] > 0
     assert "roofline" in r and r["roofline"]["traffic"] is None or isinstance(r["roofline"]["traffic"], int)
 
 

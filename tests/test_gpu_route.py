@@ -86,7 +86,7 @@ def test_route_count_and_scatter_match_oracle_rows():
     assert m.value == np.abs(v).max()
 
 
-G, TILE, N = 512, 192, 120_000          # 2 ranks x 256 rows; 192-row tiles: the block edge cuts a tile row
+G, TILE, N = 512, 192, 120_000          # 256-row (2 ranks) or ~171-row (3 ranks) blocks; 192-row tiles: block edges cut tile rows
 
 
 def _inputs():
@@ -142,26 +142,31 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_unrouted_cloud_c5_shape_matches_unsharded_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 3], ids=["two-ranks", "three-ranks:inner-rank-with-two-neighbours"])
+def test_unrouted_cloud_c5_shape_matches_unsharded_oracle(tmp_path, world):
     import torch.multiprocessing as mp
+    from pcr.distributed import row_block
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     x, y, v, w = _inputs()
     og = O.make_grid((0, 0, G, G), tile=(TILE, TILE))
     gl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=1.0, sigma_y=1.0, max_radius=4.0)
     want = [O.run(og, O.AVERAGE, x, y, v), O.run(og, O.AVERAGE, x, y, v, glyph=gl), O.run(og, O.MAX, x, y, w)]
-    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(2)]
-    assert parts[0]["own"].tolist() == [0, 256] and parts[1]["own"].tolist() == [256, 512]
-    assert int(parts[0]["halo"]) == 4 and not bool(parts[0]["local"])          # blocks cut tiles: live exchange
-    # only the Gaussian group's 2 planes exchange halos (send + recv each): the Point planes' halo rows stay empty
-    assert parts[0]["coll"].tolist() == [4, 1] and int(parts[0]["sent"]) == 2 * 4 * G * 4   # 2 planes x 4 rows x W x 4 B
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert parts[r]["own"].tolist() == list(row_block(r, world, G))
+        assert int(parts[r]["halo"]) == 4 and not bool(parts[r]["local"])      # blocks cut tiles: live exchange
+        neighbours = (1 if r > 0 else 0) + (1 if r < world - 1 else 0)
+        # only the Gaussian group's 2 planes exchange halos (send + recv each): the Point planes' halo rows stay empty
+        assert parts[r]["coll"].tolist() == [4 * neighbours, 1]
+        assert int(parts[r]["sent"]) == neighbours * 2 * 4 * G * 4               # 2 planes x 4 rows x W x 4 B per edge
     inb = (x >= 0) & (x <= G) & (y >= 0) & (y <= G)
-    assert int(parts[0]["received"]) + int(parts[1]["received"]) == int(inb.sum())   # every valid point reached an owner, once
+    assert sum(int(p["received"]) for p in parts) == int(inb.sum())             # every valid point reached an owner, once
     for b, (rt, at) in enumerate([(1e-5, 1e-6), (1e-4, 1e-6), (0, 0)]):
-        got = np.vstack([parts[0][f"b{b}"], parts[1][f"b{b}"]])
+        got = np.vstack([p[f"b{b}"] for p in parts])
         wv = want[b]
         assert np.array_equal(np.isnan(got), np.isnan(wv)), f"band {b}: NaN mask"
         m = ~np.isnan(wv)
