@@ -117,6 +117,14 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     }
 }
 
+// Points per workgroup of the count pass (a multiple of 4096).  Every block flushes its LDS histogram with up to nbins
+// global atomics, so many bins want long chunks -- but long chunks mean few blocks in flight.  Measured, k_bin_count ms:
+//   chunk          8192    16384   32768   65536   131072
+//   1376 bins (C2, 50 M points)        0.228           0.267
+//   2816 bins (16384 x 2048, 125 M)  0.672   0.648   0.630   0.647   0.697
+//   5504 bins (16384 x 4096, 250 M)  1.260   1.193   1.154   1.178   1.231
+inline int count_chunk(int nbins) { return nbins <= 2048 ? 16384 : 32768; }
+
 // ---- scan: bin starts + work items ------------------------------------------------------------
 // A bin's records are split into items of at most item_records so that one hot bin cannot
 // serialize the launch on one CU.
@@ -1090,9 +1098,13 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        const int cblocks = (int)((n + b.chunk - 1) / b.chunk);        // the count pass has its own chunk (32768 / 65536: no gain)
+        // the count pass has its own chunk: every block flushes its histogram with up to nbins global atomics, so windows
+        // with many bins count in 65536-point chunks (16384 x 4096 rows, 5504 bins: see the comment at count_chunk)
+        BinGeom bc = b;
+        bc.chunk = count_chunk(b.nbins);
+        const int cblocks = (int)((n + bc.chunk - 1) / bc.chunk);
         hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
-                           gd, b, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+                           gd, bc, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
