@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <new>
+#include <vector>
 
 using namespace pcrhip;
 
@@ -27,6 +28,16 @@ struct SharedScratch {
     hipEvent_t last = nullptr;
     bool has_last = false;
     uint64_t borrows = 0, grows = 0;
+    // moment path: the tap tables of the last glyph spec stay on the device (touched only while borrow_mu is held).
+    // A fresh pipeline's first Gaussian scatter then uploads nothing: the bench builds one pipeline per step, and a
+    // pageable host-to-device copy inside every step made the step time depend on what else the host was doing.
+    struct Taps {
+        int K = -1, r = -1;
+        float sx = 0.f, sy = 0.f;
+        float* d = nullptr;
+        size_t cap = 0;                   // floats
+        std::vector<float> host;
+    } taps;
 };
 constexpr int kMaxDevices = 64;
 SharedScratch g_scratch[kMaxDevices];
@@ -71,6 +82,34 @@ int ensure_scratch(pcr_hip_engine* e, size_t bytes) {
     e->d_scratch = static_cast<char*>(base);
     e->scratch_cap = cap;
     e->scratch_borrowed = true;
+    return PCR_HIP_OK;
+}
+
+int shared_taps(pcr_hip_engine* e, int K, int r, float sx, float sy,
+                void (*fill)(std::vector<float>&, int, int, float, float), const float** d_taps, size_t* count) {
+    PCR_REQUIRE(e->scratch_borrowed, "shared_taps: the scratch must be borrowed");
+    auto& t = g_scratch[e->device].taps;
+    if (!(t.d && t.K == K && t.r == r && t.sx == sx && t.sy == sy)) {
+        // every kernel that reads the old tables was enqueued by an earlier borrower: this stream is ordered after
+        // it (ensure_scratch); the host copy may still feed an earlier upload of this stream
+        PCR_HIP_TRY(hipStreamSynchronize(e->stream));
+        std::vector<float> next;
+        fill(next, K, r, sx, sy);
+        if (next.size() > t.cap) {
+            PCR_HIP_TRY(hipDeviceSynchronize());
+            if (t.d) (void)hipFree(t.d);
+            t.d = nullptr;
+            t.cap = 0;
+            PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.d), next.size() * sizeof(float)));
+            t.cap = next.size();
+        }
+        t.host.swap(next);
+        t.K = -1;                                                   // invalid until the upload is enqueued
+        PCR_HIP_TRY(hipMemcpyAsync(t.d, t.host.data(), t.host.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        t.K = K; t.r = r; t.sx = sx; t.sy = sy;
+    }
+    *d_taps = t.d;
+    *count = t.host.size();
     return PCR_HIP_OK;
 }
 
@@ -147,6 +186,9 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
     if (const char* t = std::getenv("PCR_HIP_ONE_PASS")) e->one_pass = std::atoi(t) != 0;
     if (const char* t = std::getenv("PCR_HIP_TUNE_SCATTER")) e->tune_scatter = std::atoi(t);
     if (const char* t = std::getenv("PCR_HIP_TUNE_B")) e->tune_b = std::atoi(t);
+    if (const char* t = std::getenv("PCR_HIP_TUNE_MOM")) e->tune_mom = std::atoi(t);
+    if (const char* t = std::getenv("PCR_HIP_TUNE_CONV")) e->tune_conv = std::atoi(t);
+    if (const char* t = std::getenv("PCR_HIP_TUNE_REC")) e->tune_rec = std::atoi(t);
     hipError_t err = hipGetDevice(&e->device);
     hipDeviceProp_t prop;
     if (err == hipSuccess) err = hipGetDeviceProperties(&prop, e->device);

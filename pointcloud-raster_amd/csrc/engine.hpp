@@ -22,6 +22,9 @@ struct pcr_hip_engine {
                                                // so that tests reach the large-grid paths on small grids)
     int tune_scatter = 0;                      // PCR_HIP_TUNE_SCATTER=3: round 1's k_bin_scatter shape (experiments only)
     int stats_scatter_chunk = 0;               // points per k_bin_scatter workgroup of the last binned scatter
+    int tune_rec = 0;                          // PCR_HIP_TUNE_REC: k_rec_scatter chunk shape (experiments only)
+    int tune_conv = 0;                         // PCR_HIP_TUNE_CONV=1: moment path convolutions on the vector ALU (experiments only)
+    int tune_mom = 0;                          // PCR_HIP_TUNE_MOM: k_tile_moments split / store kind (experiments only)
     int tune_b = 0;                            // PCR_HIP_TUNE_B=1: print k_bin_scatter's phase cycles (experiments only; synchronizes)
     bool one_pass = false;                     // PCR_HIP_ONE_PASS=1: sampled-provisioning one-pass sort for the Point glyph (opt-in)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
@@ -35,13 +38,6 @@ struct pcr_hip_engine {
     std::vector<Pending> pending;
     std::map<std::string, std::pair<uint32_t, double>> kernel_ms;
 
-    // moment path: tap tables of the last glyph spec (host copy; re-uploaded per scatter, rebuilt only on change)
-    struct TapCache {
-        int K = -1, r = -1;
-        float sx = 0.f, sy = 0.f;
-        std::vector<float> taps;               // x taps then y taps
-    } tap_cache;
-
     // scratch of the binned / moment paths: borrowed per scatter from the device-wide arena (engine.hip)
     char* d_scratch = nullptr;
     size_t scratch_cap = 0;
@@ -52,6 +48,10 @@ namespace pcrhip {
 
 int ensure_scratch(pcr_hip_engine* e, size_t bytes);
 void release_scratch(pcr_hip_engine* e);
+// Device-resident tap tables of the moment path, shared by the engines of a device (engine.hip); call with the scratch
+// borrowed.  fill(tables, K, r, sx, sy) builds the host copy when the glyph spec changed.
+int shared_taps(pcr_hip_engine* e, int K, int r, float sx, float sy,
+                void (*fill)(std::vector<float>&, int, int, float, float), const float** d_taps, size_t* count);
 
 // Brackets one kernel launch with events when profiling is on.
 struct ScopedKernelTimer {

@@ -835,61 +835,63 @@ k_sub_scatter(int sup_shift, const uint2* __restrict__ rec, const BinItem* __res
 // run time of k_tile_line).  Here they are read once, coalesced, and travel with the record.  No LDS
 // staging of the data: a lane stores its own record (two 16-byte stores); the records of one (block, bin)
 // run are adjacent in memory and meet in L2.
-constexpr int kRecKeys = 16;                    // keys per thread: 16384-point chunks whatever the bin count,
-constexpr int kRecChunk = kRecKeys * kThreads;  // so that a (block, bin) run is a few records long
-constexpr int kRecBatch = 8;                    // records assembled per thread at a time
-
-__global__ void __launch_bounds__(kThreads)
+// Shape: KEYS keys per thread (a KEYS x 1024-point chunk whatever the bin count, so that a (block, bin) run is a few
+// records long), BATCH records assembled per thread at a time.  A key is kept as bin << 16 | rank-in-the-chunk's-run
+// (one register per point; the local cell is not part of a glyph record).
+template <int THREADS, int KEYS, int BATCH>
+__global__ void __launch_bounds__(THREADS)
 k_rec_scatter(BinGeom b, GlyphDev gl, const unsigned* __restrict__ keys, const double* __restrict__ x,
               const double* __restrict__ y, const float* __restrict__ v, uint64_t n,
               unsigned* __restrict__ cursor, GlyphRec* __restrict__ records) {
+    static_assert(KEYS % BATCH == 0 && KEYS * THREADS <= 65536, "chunk shape");
     extern __shared__ unsigned lds_u32[];
     unsigned* hist = lds_u32;                   // [nbins]  then reused as the bin's global base
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
+    for (int i = threadIdx.x; i < b.nbins; i += THREADS) hist[i] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * kRecChunk;
+    const uint64_t base = (uint64_t)blockIdx.x * (KEYS * THREADS);
     const float* ch0 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.sigma_x : gl.direction;
     const float* ch1 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.sigma_y : gl.half_length;
     const float* ch2 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.rotation : nullptr;
-    unsigned key[kRecKeys], rank[kRecKeys];
+    unsigned kr[KEYS];
 #pragma unroll
-    for (int k = 0; k < kRecKeys; ++k) {
-        const uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
-        key[k] = i < n ? keys[i] : 0xFFFFFFFFu;
+    for (int k = 0; k < KEYS; ++k) {
+        const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
+        kr[k] = i < n ? keys[i] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int k = 0; k < kRecKeys; ++k) {
-        rank[k] = 0;
-        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
+    for (int k = 0; k < KEYS; ++k) {
+        if (kr[k] == 0xFFFFFFFFu) continue;
+        const unsigned bin = kr[k] >> kLcellBits;
+        kr[k] = (bin << 16) | atomicAdd(&hist[bin], 1u);
     }
     __syncthreads();
     {
         constexpr int kRes = 4;                               // a lane's reservations are issued back to back
-        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * kThreads) {
+        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * THREADS) {
             unsigned c[kRes], gp[kRes];
 #pragma unroll
             for (int u = 0; u < kRes; ++u) {
-                const int i = i0 + u * kThreads;
+                const int i = i0 + u * THREADS;
                 c[u] = i < b.nbins ? hist[i] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < kRes; ++u) {
                 gp[u] = 0;
-                if (c[u]) gp[u] = atomicAdd(&cursor[i0 + u * kThreads], c[u]);
+                if (c[u]) gp[u] = atomicAdd(&cursor[i0 + u * THREADS], c[u]);
             }
 #pragma unroll
             for (int u = 0; u < kRes; ++u)
-                if (c[u]) hist[i0 + u * kThreads] = gp[u];  // now: where this block's run of the bin starts
+                if (c[u]) hist[i0 + u * THREADS] = gp[u];  // now: where this block's run of the bin starts
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k0 = 0; k0 < kRecKeys; k0 += kRecBatch) {
-        double wx[kRecBatch], wy[kRecBatch];
-        float val[kRecBatch], c0[kRecBatch], c1[kRecBatch], c2[kRecBatch];
+    for (int k0 = 0; k0 < KEYS; k0 += BATCH) {
+        double wx[BATCH], wy[BATCH];
+        float val[BATCH], c0[BATCH], c1[BATCH], c2[BATCH];
 #pragma unroll
-        for (int u = 0; u < kRecBatch; ++u) {   // the batch's loads in flight before the first store
-            const uint64_t i = base + (uint64_t)(k0 + u) * kThreads + threadIdx.x;
+        for (int u = 0; u < BATCH; ++u) {       // the batch's loads in flight before the first store
+            const uint64_t i = base + (uint64_t)(k0 + u) * THREADS + threadIdx.x;
             const uint64_t ic = i < n ? i : n - 1;
             wx[u] = x[ic];
             wy[u] = y[ic];
@@ -899,12 +901,12 @@ k_rec_scatter(BinGeom b, GlyphDev gl, const unsigned* __restrict__ keys, const d
             c2[u] = ch2 ? ch2[ic] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < kRecBatch; ++u) {
-            const unsigned kk = key[k0 + u];
+        for (int u = 0; u < BATCH; ++u) {
+            const unsigned kk = kr[k0 + u];
             if (kk == 0xFFFFFFFFu) continue;
             GlyphRec r;
             r.x = wx[u]; r.y = wy[u]; r.v = val[u]; r.c0 = c0[u]; r.c1 = c1[u]; r.c2 = c2[u];
-            records[hist[kk >> kLcellBits] + rank[k0 + u]] = r;
+            records[hist[kk >> 16] + (kk & 0xFFFFu)] = r;
         }
     }
 }
@@ -952,9 +954,11 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
     float* t_min = t_max + ((MASK & 4) ? cells : 0);
 
     // records: kUnroll independent 8-byte loads per lane, double-buffered -- the next batch is in flight
-    // (64 KB per CU) while the current one goes through the dependent LDS atomics, and the first batch is
-    // issued before the tile is even initialised.
-    constexpr int kUnroll = 8;
+    // (32 KB per CU) while the current one goes through the dependent LDS atomics, and the first batch is
+    // issued before the tile is even initialised.  Batches of 4 beat 8, 12 and 16 (0.142 vs 0.148 / 0.149 /
+    // 0.152 ms on C2, same box, alternating runs): the kernel is not latency-bound, shorter batches interleave
+    // the loads and the LDS atomics more finely.
+    constexpr int kUnroll = 4;
     const uint2* rec = records + it.first;
     uint2 cur[kUnroll], nxt[kUnroll];
     auto fetch = [&](uint2 (&r)[kUnroll], unsigned j0) {
@@ -1115,11 +1119,18 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         ScopedKernelTimer t(e, "k_rec_scatter");
         GlyphRec* d_rec = reinterpret_cast<GlyphRec*>(s + o_rec);
         const size_t lds = (size_t)b.nbins * 4;
-        const int rblocks = (int)((n + kRecChunk - 1) / kRecChunk);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rec_scatter),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_rec_scatter, dim3(rblocks), dim3(kThreads), lds, e->stream, b, *gl, d_keys, x, y, v, n,
-                           d_cursor, d_rec);
+        auto launch = [&](auto kernel, int threads, int chunk) {
+            const int rblocks = (int)((n + chunk - 1) / chunk);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kernel, dim3(rblocks), dim3(threads), lds, e->stream, b, *gl, d_keys, x, y, v, n, d_cursor, d_rec);
+        };
+        // Shape, measured on MI355X (Line hl=16, 50 M points, 3249 bins; same box, alternating runs, tools/ab_env.sh):
+        // 256 threads x 16 keys with all 16 payload loads in flight (three workgroups per CU)  1.28-1.32 ms;
+        // 1024 x 16 in batches of 8 (one workgroup per CU, the first shape)                     1.36-1.38 ms;
+        // longer chunks (1024 x 24 / 32) are slower, 128-thread groups too.  The kernel's time also moves by +-10 %
+        // from process to process at the same shape (placement of the arrays in HBM).
+        if (e->tune_rec == 1) launch(&k_rec_scatter<1024, 16, 8>, 1024, 16 * 1024);     // experiments: PCR_HIP_TUNE_REC=1
+        else launch(&k_rec_scatter<256, 16, 16>, 256, 16 * 256);
         out->records = nullptr;
         out->grecords = d_rec;
     } else {

@@ -39,7 +39,6 @@ constexpr int kThreads = 1024;        // count / scatter passes
 constexpr int kMomThreads = 512;      // per-tile moment reduction (register heavy)
 constexpr int kPad = 20;              // zero padding of the tap tables (16-output windows, 4 source rows per step)
 constexpr int kTileW = 128, kTileH = 72;                 // 9216 cells: two u32 tables + index list fit the LDS
-constexpr int kTileCells = kTileW * kTileH;
 constexpr int kSortChunk = 32768;                        // records sorted per round inside LDS (u16 positions: 64 KB)
 constexpr int kMaxK = 9;
 constexpr double kTruncationBound = 5e-5;      // make_plan: rigorous bound on the relative error of any weight
@@ -267,37 +266,50 @@ k_mom_scatter(GridDev g, BinGeom b, const unsigned* __restrict__ keys, const dou
 }
 
 // ---- pass C: per-tile moments: sort the bin's records by cell in LDS, reduce per cell in registers ----
-template <int K, unsigned MASK>
+// A bin (128 x 72 cells, ~27 K records = 442 KB) is shared by kMomSplit = 4 workgroups, each owning 18 of its 72 rows.
+// The reduction fetches a cell's records by their sorted position -- random 16-byte reads inside the bin's record
+// range.  With one workgroup per bin the 32 CUs of an XCD worked on 32 bins (14 MB of records against 4 MB of L2) and
+// every gathered record cost a whole 128-byte line from HBM: 5.7 GB fetched for 0.8 GB of records, the kernel ran at
+// the fetch bandwidth (profiles/r02_gauss16_rocprof.md).  The four workgroups of a bin get consecutive dispatch slots
+// on ONE XCD (workgroups go to the XCDs round-robin: blockIdx = (slot * 8 + xcd)), so an XCD holds 8 bins = 3.5 MB at a
+// time and the gathers hit its L2; every workgroup streams the whole bin's cell indices (L2 hits for three of the
+// four) and keeps the records of its own rows.
+template <int K, unsigned MASK, int kMomSplit, bool NT>
 __global__ void __launch_bounds__(kMomThreads)
 k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* __restrict__ records,
                const unsigned* __restrict__ bin_start, float* __restrict__ mom_v, float* __restrict__ mom_w,
                int64_t plane_stride) {
     constexpr int P = (K + 1) * (K + 2) / 2;
+    constexpr int kPartRows = kTileH / kMomSplit, kPartCells = kTileW * kPartRows;       // split 4: 18 rows, 2304 cells
+    static_assert(kTileH % kMomSplit == 0, "parts are whole rows");
     extern __shared__ unsigned lds_u[];
-    unsigned* off = lds_u;                         // [kTileCells + 1]
-    unsigned* cur = off + kTileCells + 1;          // [kTileCells]
-    unsigned short* idx = reinterpret_cast<unsigned short*>(cur + kTileCells);   // [kSortChunk] record position inside the round
+    unsigned* off = lds_u;                         // [kPartCells + 1]
+    unsigned* cur = off + kPartCells + 1;          // [kPartCells]
+    unsigned short* idx = reinterpret_cast<unsigned short*>(cur + kPartCells);   // [kSortChunk] record position inside the round
     __shared__ unsigned wave_tot[kMomThreads / 64];
 
-    const int bin = blockIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int part = slot % kMomSplit, bin = (slot / kMomSplit) * 8 + xcd;
+    if (bin >= b.nbins) return;
     const unsigned first = bin_start[bin], count = bin_start[bin + 1] - first;
     const int bx = bin % b.bins_x, by = bin / b.bins_x;
-    const int c0 = bx * kTileW, r0 = by * kTileH;
-    const int w = min(kTileW, g.W - c0), h = min(kTileH, g.st_rows - r0);
+    const int c0 = bx * kTileW, r0 = by * kTileH + part * kPartRows;
+    const int w = min(kTileW, g.W - c0), h = min(kPartRows, g.st_rows - r0);          // h <= 0: nothing to write
+    const unsigned cell0 = (unsigned)(part * kPartCells);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kPer = kTileCells / kMomThreads;           // 18 cells per thread in the scan
+    constexpr int kPer = (kPartCells + kMomThreads - 1) / kMomThreads;     // 5 cells per thread in the scan (the last own fewer)
 
     for (unsigned cbase = 0; cbase == 0 || cbase < count; cbase += kSortChunk) {
         const unsigned cn = min((unsigned)kSortChunk, count - cbase);
         const uint4* rec = records + first + cbase;
-        for (int i = threadIdx.x; i < kTileCells; i += kMomThreads) cur[i] = 0;
+        for (int i = threadIdx.x; i < kPartCells; i += kMomThreads) cur[i] = 0;
         __syncthreads();
         // ONE pass over the records' cell indices: the LDS atomic that counts a cell's records also returns the
         // record's rank inside its cell, and (cell, rank) stays in a register until the scan has turned the counts into
-        // offsets -- the records are not read a second time (they were: 0.8 GB of the kernel's 6.5 GB of fetches), and
-        // the second round of LDS atomics is gone.  Eight independent loads in flight per lane.
+        // offsets -- the records are not read a second time, and there is no second round of LDS atomics.
+        // Eight independent loads in flight per lane.
         constexpr int kTrips = kSortChunk / (8 * kMomThreads);       // 8: up to 64 records per thread and round
-        unsigned cr[kTrips * 8];                                     // cell | rank << 16 (both < 2^15.. 2^16)
+        unsigned cr[kTrips * 8];                                     // cell | rank << 16 (both < 2^16)
 #pragma unroll
         for (int it = 0; it < kTrips; ++it) {
             const unsigned j0 = threadIdx.x + it * 8 * kMomThreads;
@@ -305,18 +317,19 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const unsigned j = j0 + u * kMomThreads;
-                lc[u] = j < cn ? rec[j].x : 0xFFFFFFFFu;
+                lc[u] = j < cn ? rec[j].x - cell0 : 0xFFFFFFFFu;     // cells of other parts wrap far above kPartCells
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 cr[it * 8 + u] = 0xFFFFFFFFu;
-                if (lc[u] != 0xFFFFFFFFu) cr[it * 8 + u] = lc[u] | (atomicAdd(&cur[lc[u]], 1u) << 16);
+                if (lc[u] < (unsigned)kPartCells) cr[it * 8 + u] = lc[u] | (atomicAdd(&cur[lc[u]], 1u) << 16);
             }
         }
         __syncthreads();
         // exclusive scan of cur -> off (thread t owns cells [t*kPer, (t+1)*kPer))
+        const int s_lo = min((int)threadIdx.x * kPer, kPartCells), s_hi = min(s_lo + kPer, kPartCells);
         unsigned s = 0;
-        for (int i = 0; i < kPer; ++i) s += cur[threadIdx.x * kPer + i];
+        for (int c = s_lo; c < s_hi; ++c) s += cur[c];
         unsigned incl = s;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -327,13 +340,12 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
         __syncthreads();
         unsigned run = incl - s;
         for (int wv = 0; wv < wave; ++wv) run += wave_tot[wv];
-        for (int i = 0; i < kPer; ++i) {
-            int c = threadIdx.x * kPer + i;
+        for (int c = s_lo; c < s_hi; ++c) {
             unsigned cc = cur[c];
             off[c] = run;
             run += cc;
         }
-        if (threadIdx.x == kMomThreads - 1) off[kTileCells] = run;
+        if (threadIdx.x == kMomThreads - 1) off[kPartCells] = run;
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < kTrips; ++it)
@@ -344,14 +356,35 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
             }
         __syncthreads();
 
-        // per cell: fold its records into P (x2) moments held in registers, write the planes
-        for (int cell = threadIdx.x; cell < kTileCells; cell += kMomThreads) {
+        // per cell: fold its records into P (x2) moments held in registers, write the planes.  The first four
+        // records of the thread's NEXT cell are fetched before the current cell is folded: the gather is a chain of
+        // LDS read -> address -> global load, and with eight waves per CU nothing else hides it.
+        struct CellRecs { unsigned e0, e1; uint4 r[4]; };
+        auto fetch = [&](int cell) {
+            CellRecs c;
+            c.e0 = c.e1 = 0;
+            c.r[0] = c.r[1] = c.r[2] = c.r[3] = make_uint4(0u, 0u, 0u, 0u);
+            if (cell < kPartCells) {
+                c.e0 = off[cell];
+                c.e1 = off[cell + 1];
+                if (c.e1 > c.e0) {
+                    const unsigned last = c.e1 - 1;                // clamped, not predicated: plain global loads
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c.r[q] = rec[idx[min(c.e0 + q, last)]];
+                }
+            }
+            return c;
+        };
+        CellRecs nxt = fetch(threadIdx.x);
+        for (int cell = threadIdx.x; cell < kPartCells; cell += kMomThreads) {
+            const CellRecs cr4 = nxt;
+            nxt = fetch(cell + kMomThreads);
             const int ly = cell / kTileW, lx = cell - ly * kTileW;
             if (lx >= w || ly >= h) continue;
             float av[P], aw[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) { av[p] = 0.f; aw[p] = 0.f; }
-            const unsigned e0 = off[cell], e1 = off[cell + 1];
+            const unsigned e0 = cr4.e0, e1 = cr4.e1;
             // fold one record into the P (x2) accumulators
             auto fold = [&](const uint4& rc) {
                 const float val = __uint_as_float(rc.y), sx = __uint_as_float(rc.z), sy = __uint_as_float(rc.w);
@@ -379,11 +412,17 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
                     }
                 }
             };
-            // a cell holds ~3 points on average: fetch up to four records with independent loads,
-            // then fold them (otherwise every record costs one dependent L2/HBM latency)
-            for (unsigned e = e0; e < e1; e += 4) {
+            if (e1 > e0) {
+                const unsigned left0 = e1 - e0;
+                fold(cr4.r[0]);
+                if (left0 > 1) fold(cr4.r[1]);
+                if (left0 > 2) fold(cr4.r[2]);
+                if (left0 > 3) fold(cr4.r[3]);
+            }
+            // a cell holds ~3 points on average; the rest of a crowded cell, four independent loads at a time
+            for (unsigned e = e0 + 4; e < e1; e += 4) {
                 const unsigned left = e1 - e;
-                const unsigned last = e1 - 1;                      // clamped, not predicated: plain global loads
+                const unsigned last = e1 - 1;
                 const uint4 b0 = rec[idx[e]];
                 const uint4 b1 = rec[idx[min(e + 1, last)]];
                 const uint4 b2 = rec[idx[min(e + 2, last)]];
@@ -395,10 +434,16 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
             }
             const int64_t gcell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
             if (cbase == 0) {
+                // written once, read by the column pass much later: streamed past the L2
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    if (MASK & 1) mom_v[p * plane_stride + gcell] = av[p];
-                    if (MASK & 2) mom_w[p * plane_stride + gcell] = aw[p];
+                    if (NT) {
+                        if (MASK & 1) __builtin_nontemporal_store(av[p], mom_v + p * plane_stride + gcell);
+                        if (MASK & 2) __builtin_nontemporal_store(aw[p], mom_w + p * plane_stride + gcell);
+                    } else {
+                        if (MASK & 1) mom_v[p * plane_stride + gcell] = av[p];
+                        if (MASK & 2) mom_w[p * plane_stride + gcell] = aw[p];
+                    }
                 }
             } else if (e1 > e0) {
 #pragma unroll
@@ -578,6 +623,158 @@ k_conv_col(GridDev g, int K, int r, int yblocks_per_tile, const float* __restric
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         if (y0 + j < t_hi) uo[(int64_t)(y0 + j) * g.W + x] = conv_out(acc, j);
+}
+
+// The column pass on the matrix cores.  The sweep of one wave -- 16 output rows x 64 columns against its
+// 16 + 2r source rows -- is a banded Toeplitz product: out[i][j] = sum_c T[i][c] * src[c][j], T[i][c] = tap(i - c).
+// v_mfma_f32_16x16x4_f32 takes f32 operands and accumulates in f32 (no precision to give up) at the packed-FMA
+// rate, but needs NO vector-ALU instruction per product: per step of four source rows a lane reads one tap and
+// four sources from LDS and issues four MFMAs (the four 16-column blocks share the tap operand).  The zero band
+// of T costs (16 + 2r + 3) / (2r + 1) - 1 = 23 % extra products at r = 48; the vector sweep above reached 43 % of
+// the FMA rate.  Operand lane maps (one f32 per lane): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C[row = 4 (lane >> 4) + reg][col = lane & 15].
+// LDS rows are 80 floats apart: the four source rows a B operand touches then fall on disjoint banks.
+typedef float pcr_f4 __attribute__((ext_vector_type(4)));
+constexpr int kColStride = 80;
+
+// Staging (NI > 0; needs W % 4 == 0): a lane moves FOUR consecutive columns of one row per load (16-byte global
+// load, 16-byte LDS store), a wave four rows per instruction -- NI = ceil(rows / 16) loads per lane and plane, kept
+// in flight in registers behind the sweep of the previous plane.  The first version staged one float per lane with
+// wave-uniform row pointers and validity (as k_conv_col does): ~670 scalar instructions per plane and wave, as much
+// issue time as the MFMAs themselves (profiles/r02_conv_mfma.md).  NI == 0: plain float loop, any width.
+template <int NI>
+__global__ void __launch_bounds__(256)
+k_conv_col_mfma(GridDev g, int K, int r, int yblocks_per_tile, const float* __restrict__ taps_y,
+                const float* __restrict__ mom, int64_t plane_stride, float* __restrict__ u_out) {
+    extern __shared__ float lds_f[];                   // [48 + 4 steps][kColStride] sources | (K + 1) tap tables
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x = blockIdx.x * 64 + lane;
+    const int trow = blockIdx.y / yblocks_per_tile, yb = blockIdx.y - trow * yblocks_per_tile;
+    const int t_lo = max(trow * g.th - g.st_r0, 0), t_hi = min(min((trow + 1) * g.th, g.H) - g.st_r0, g.st_rows);
+    const int Y0 = t_lo + yb * 64;
+    if (Y0 >= t_hi) return;                            // whole workgroup
+    const int steps = (16 + 2 * r + 3) >> 2;           // four source rows per step; rows past 16 + 2r meet zero taps
+    const int nsrc = 64 + 2 * r, nalloc = 48 + 4 * steps;   // LDS row s <-> window row Y0 - r + s; the sweep of the last
+                                                            // wave ends at row 48 + 4 steps - 1 (0..3 zero rows of slack)
+    const int tap_w = 2 * r + 1 + 2 * kPad;
+    float* lds_taps = lds_f + nalloc * kColStride;
+    for (int i = threadIdx.x; i < (K + 1) * tap_w; i += 256) lds_taps[i] = taps_y[i];
+    pcr_f4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pcr_f4{0.f, 0.f, 0.f, 0.f};
+    const bool xin = x < g.W;
+    const bool active = Y0 + wave * 16 < t_hi;
+    const int j16 = lane & 15, kg = lane >> 4;
+
+    // staging map: LDS row 16 it + 4 wave + kg, columns 4 j16 .. 4 j16 + 3
+    const int srow0 = 4 * wave + kg, c4 = 4 * j16;
+    const bool cin = blockIdx.x * 64 + c4 < g.W;       // W % 4 == 0: the four columns are inside together
+    const int lo_s = t_lo - (Y0 - r), hi_s = min(t_hi - (Y0 - r), nsrc);       // valid LDS rows [lo_s, hi_s)
+    pcr_f4 pre[NI > 0 ? NI : 1];
+    auto issue = [&](int pair) {                       // moment planes are stored in the order the pairs are visited
+        const float* __restrict__ base = mom + (int64_t)pair * plane_stride + (int64_t)(Y0 - r + srow0) * g.W +
+                                         (blockIdx.x * 64 + c4);
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int sr = srow0 + 16 * it;
+            const bool ok = cin && sr >= lo_s && sr < hi_s;
+            pre[it] = ok ? *reinterpret_cast<const pcr_f4*>(base + (int64_t)16 * it * g.W) : pcr_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // One workgroup walks ALL pairs (k, l), l = 0..K-k, of its 64 x 64 outputs: the load of the next plane is always
+    // in flight behind the current sweep (one exposed memory latency per workgroup, not one per k).
+    const int npairs = (K + 1) * (K + 2) / 2;
+    if (NI > 0) issue(0);
+    int k = 0, l = 0;
+    for (int pair = 0; pair < npairs; ++pair) {
+        __syncthreads();                               // the previous plane's readers (and the U_k hand-over) are done
+        if (NI > 0) {
+            float* dst = lds_f + srow0 * kColStride + c4;
+#pragma unroll
+            for (int it = 0; it < NI; ++it)
+                if (srow0 + 16 * it < nalloc) *reinterpret_cast<pcr_f4*>(dst + 16 * it * kColStride) = pre[it];
+        } else {
+            const float* __restrict__ plane = mom + (int64_t)pair * plane_stride;
+            const int xc = xin ? x : 0;
+            for (int s0 = wave; s0 < nalloc; s0 += 32) {
+                float vals[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sr = s0 + 4 * u, yy = Y0 - r + sr;
+                    const float* __restrict__ rowp = plane + (int64_t)yy * g.W;
+                    vals[u] = (sr < nsrc && yy >= t_lo && yy < t_hi) ? rowp[xc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + 4 * u < nalloc) lds_f[(s0 + 4 * u) * kColStride + lane] = vals[u];
+            }
+        }
+        __syncthreads();
+        if (NI > 0 && pair + 1 < npairs) issue(pair + 1);
+        if (active) {
+            // output row i = j16 of this wave, source c = 4 s + kg (LDS row 16 wave + c): tap index i - c
+            const float* ta = lds_taps + l * tap_w + kPad + 2 * r + j16 - kg;
+            const float* sb = lds_f + (16 * wave + kg) * kColStride + j16;
+            // Software-pipelined over two operand sets: the reads of step s + 1 are issued before the MFMAs of step s.
+            // (The index goes through an opaque asm and the loaded set is "used" by an empty asm after the MFMAs --
+            // otherwise the compiler folds the prefetch back into "load, wait, use" at the top of the next iteration.)
+            struct Ops { float a, b0, b1, b2, b3; };
+            auto load = [&](int sidx) {
+                int sn = min(sidx, steps - 1);                      // past the end: re-read the last step (unused)
+                asm volatile("" : "+s"(sn));
+                const float* row = sb + 4 * sn * kColStride;
+                return Ops{ta[-4 * sn], row[0], row[16], row[32], row[48]};
+            };
+            auto mac = [&](const Ops& o) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a, o.b3, acc[3], 0, 0, 0);
+            };
+            auto pin = [](Ops& o) {
+                __builtin_amdgcn_sched_barrier(0);                  // after the MFMAs above, not in their middle
+                asm volatile("" : "+v"(o.a), "+v"(o.b0), "+v"(o.b1), "+v"(o.b2), "+v"(o.b3));
+            };
+            Ops p = load(0), q;
+            for (int s4 = 0; s4 < steps; s4 += 2) {
+                q = load(s4 + 1);
+                __builtin_amdgcn_sched_barrier(0);                  // reads first, then the MFMAs that cover their latency
+                mac(p);
+                pin(q);
+                p = load(s4 + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s4 + 1 < steps) mac(q);
+                pin(p);
+            }
+        }
+        if (l < K - k) { ++l; continue; }
+        // U_k is complete.  It leaves through LDS (rows 16 wave .. 16 wave + 15 of the staging area, free once every
+        // wave has finished its sweep): an accumulator holds 4 rows x 16 columns per lane group, the planes want
+        // whole 256-byte row segments per store.
+        __syncthreads();
+        if (active) {
+            float* ob = lds_f + (16 * wave + 4 * kg) * kColStride + j16;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ob[q * kColStride + cb * 16] = acc[cb][q];
+                acc[cb] = pcr_f4{0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (xin) {
+                float* uo = u_out + (int64_t)k * plane_stride;
+                const int y0 = Y0 + wave * 16;
+                const float* rb = lds_f + 16 * wave * kColStride + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (y0 + j < t_hi) uo[(int64_t)(y0 + j) * g.W + x] = rb[j * kColStride];
+            }
+        }
+        ++k;
+        l = 0;
+    }
 }
 
 // Row pass + accumulate: out[y][x] += sum_k sum_dx A_k(dx) U_k[y][x - dx], sources inside the output
@@ -861,11 +1058,27 @@ void fill_taps(std::vector<float>& t, int K, int r, double s2) {
 template <int K, unsigned MASK>
 void launch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                     float* mom_v, float* mom_w, int64_t stride) {
-    const size_t lds = ((size_t)kTileCells * 2 + 1) * sizeof(unsigned) + (size_t)kSortChunk * sizeof(unsigned short) + 16;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_moments<K, MASK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tile_moments<K, MASK>), dim3(p.bins.nbins), dim3(kMomThreads), lds, e->stream, gw,
-                       p.bins, p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
+    auto launch = [&](auto kernel, int split) {
+        const int part_cells = kTileW * (kTileH / split);
+        const size_t lds = ((size_t)part_cells * 2 + 1) * sizeof(unsigned) + (size_t)kSortChunk * sizeof(unsigned short) + 16;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int blocks = ((p.bins.nbins + 7) / 8) * 8 * split;     // blockIdx = (bin group * split + part) * 8 + xcd
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kMomThreads), lds, e->stream, gw,
+                           p.bins, p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
+    };
+    // One workgroup per bin.  Sharing a bin between 2 or 4 workgroups of one XCD (rows split, PCR_HIP_TUNE_MOM = 2 / 4)
+    // takes the HBM fetches of this kernel from 5.7 GB to 0.85 GB -- the gathers then hit the XCD's L2 -- and makes
+    // it SLOWER (1.07 -> 1.22 / 1.43 ms at sigma = 16): every part streams the whole bin's cell indices, and the
+    // kernel was waiting on the gather's latency, not on bandwidth (profiles/r02_moments_split.md).
+    if constexpr (K == 3 || K == 5) {
+        switch (e->tune_mom) {
+            case 2: return launch(&k_tile_moments<K, MASK, 2, true>, 2);
+            case 4: return launch(&k_tile_moments<K, MASK, 4, true>, 4);
+            case 9: return launch(&k_tile_moments<K, MASK, 1, false>, 1);
+            default: break;
+        }
+    }
+    launch(&k_tile_moments<K, MASK, 1, true>, 1);
 }
 
 template <unsigned MASK>
@@ -919,7 +1132,6 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     const size_t o_start = off;  off += align256((size_t)(max_bins + 1) * 4);
     const size_t o_cursor = off; off += align256((size_t)max_bins * 4);
     const size_t o_fbc = off;    off += 256;
-    const size_t o_taps = off;   off += align256((size_t)2 * (p.K + 1) * tap_w * 4);
     const size_t o_keys = off;   off += align256((size_t)n * 4);
     const size_t o_fbl = off;    off += align256((size_t)n * 4);
     const size_t o_rec = off;    off += align256((size_t)n * 16);
@@ -932,36 +1144,35 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     unsigned* d_start = reinterpret_cast<unsigned*>(s + o_start);
     unsigned* d_cursor = reinterpret_cast<unsigned*>(s + o_cursor);
     unsigned* d_fbc = reinterpret_cast<unsigned*>(s + o_fbc);
-    float* d_taps = reinterpret_cast<float*>(s + o_taps);
     unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
     unsigned* d_fbl = reinterpret_cast<unsigned*>(s + o_fbl);
     uint4* d_rec = reinterpret_cast<uint4*>(s + o_rec);
     float* d_mom = reinterpret_cast<float*>(s + o_mom);
     float* d_u = reinterpret_cast<float*>(s + o_u);
 
-    // tap tables: x taps then y taps
+    // tap tables: x taps then y taps, resident on the device while the glyph spec stays the same
     const float sx = gl.def_sigma_x * (float)e->gd.inv_csx, sy = gl.def_sigma_y * (float)e->gd.inv_csy;
-    auto& tc = e->tap_cache;
-    if (tc.K != p.K || tc.r != p.r || tc.sx != sx || tc.sy != sy) {
-        // the previous upload may still be in flight from the old vector
-        PCR_HIP_TRY(hipStreamSynchronize(e->stream));
-        std::vector<float> tx, ty;
-        fill_taps(tx, p.K, p.r, (double)sx * sx);
-        fill_taps(ty, p.K, p.r, (double)sy * sy);
-        tc.taps = tx;
-        tc.taps.insert(tc.taps.end(), ty.begin(), ty.end());
-        tc.K = p.K; tc.r = p.r; tc.sx = sx; tc.sy = sy;
-    }
-    // the host copy lives in the engine: no synchronisation needed after the upload
-    PCR_HIP_TRY(hipMemcpyAsync(d_taps, tc.taps.data(), tc.taps.size() * 4, hipMemcpyHostToDevice, e->stream));
+    const float* d_taps = nullptr;
+    size_t ntaps = 0;
+    rc = shared_taps(e, p.K, p.r, sx, sy,
+                     [](std::vector<float>& t, int K, int r, float tsx, float tsy) {
+                         std::vector<float> ty;
+                         fill_taps(t, K, r, (double)tsx * tsx);
+                         fill_taps(ty, K, r, (double)tsy * tsy);
+                         t.insert(t.end(), ty.begin(), ty.end());
+                     },
+                     &d_taps, &ntaps);
+    if (rc) return rc;
     const float* taps_x = d_taps;
-    const float* taps_y = d_taps + tc.taps.size() / 2;
+    const float* taps_y = d_taps + ntaps / 2;
 
     // shapes that do not depend on the band
     const GridDev& ge = e->gd;
     const int yblocks = (std::min(ge.th, ge.H) + 63) / 64;
     const size_t col_lds = (size_t)(64 + 2 * p.r + 4) * 64 * sizeof(float);
     const int col_rows_per_wave = (64 + 2 * p.r + 4 + 3) / 4;
+    const int col_rows_mfma = 48 + 4 * ((16 + 2 * p.r + 3) >> 2);       // three workgroups per CU at r = 48, K = 3
+    const size_t col_lds_mfma = ((size_t)col_rows_mfma * kColStride + (size_t)(p.K + 1) * tap_w) * sizeof(float);
     // row pass shape: the strip width (1024 / 256 / 64 columns) that wastes the fewest lanes on this tile width
     const int eff_tw = std::min(ge.tw, ge.W);
     int lpr_shift = 6;
@@ -1028,6 +1239,10 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         }
         // convolutions, per plane kind
         const dim3 col_grid((g.W + 63) / 64, g.tiles_y * yblocks, p.K + 1);
+        auto launch_col_mfma = [&](auto kernel, const float* src) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds_mfma);
+            hipLaunchKernelGGL(kernel, dim3(col_grid.x, col_grid.y, 1), dim3(256), col_lds_mfma, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
+        };
         auto launch_col = [&](auto kernel, const float* src) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
             hipLaunchKernelGGL(kernel, col_grid, dim3(256), col_lds, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
@@ -1044,7 +1259,17 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
             outp += win_off;
             {
                 ScopedKernelTimer t(e, "k_conv_col");
-                if (col_rows_per_wave <= 24) launch_col(&k_conv_col<24>, mom);
+                // matrix-core sweep from r = 24 (15 % faster at r = 48, 7 % slower at r = 12 where the pass is HBM-bound
+                // either way); PCR_HIP_TUNE_CONV = 1 / 2 force the vector-ALU / the MFMA sweep (experiments)
+                if (e->tune_conv == 2 || (e->tune_conv != 1 && p.r >= 24)) {
+                    const int ni = (col_rows_mfma + 15) / 16;         // 16-row staging rounds
+                    const bool vec = g.W % 4 == 0 && cells % 4 == 0 && (reinterpret_cast<uintptr_t>(mom) & 15) == 0;
+                    if (vec && ni <= 6) launch_col_mfma(&k_conv_col_mfma<6>, mom);
+                    else if (vec && ni <= 8) launch_col_mfma(&k_conv_col_mfma<8>, mom);
+                    else if (vec && ni <= 11) launch_col_mfma(&k_conv_col_mfma<11>, mom);
+                    else if (vec && ni <= 14) launch_col_mfma(&k_conv_col_mfma<14>, mom);
+                    else launch_col_mfma(&k_conv_col_mfma<0>, mom);
+                } else if (col_rows_per_wave <= 24) launch_col(&k_conv_col<24>, mom);
                 else if (col_rows_per_wave <= 32) launch_col(&k_conv_col<32>, mom);
                 else if (col_rows_per_wave <= 48) launch_col(&k_conv_col<48>, mom);
                 else launch_col(&k_conv_col<0>, mom);
