@@ -95,7 +95,9 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
                 const uint64_t i = base + 2ull * (p0 + u * kCountThreads);
                 unsigned ka = handle(i, xs[u].x, ys[u].x);
                 unsigned kb = handle(i + 1, xs[u].y, ys[u].y);
-                k2[p0 + u * kCountThreads] = make_uint2(ka, kb);
+                // (non-temporal: 200 MB of keys, read once by pass B; C2 step -0.5 %)
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                __builtin_nontemporal_store(u2v{ka, kb}, reinterpret_cast<u2v*>(k2 + p0 + u * kCountThreads));
             }
         }
     } else {
@@ -1036,8 +1038,13 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
                 if ((MASK & 4) && n4) g4 = *reinterpret_cast<const float4*>(pl.mx + cell);
                 if ((MASK & 8) && n8) g8 = *reinterpret_cast<const float4*>(pl.mn + cell);
             }
-            if ((MASK & 1) && n1) { g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w; *reinterpret_cast<float4*>(pl.sum + cell) = g1; }
-            if ((MASK & 2) && n2) { g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w; *reinterpret_cast<float4*>(pl.wgt + cell) = g2; }
+            // the Sum / Count planes leave with non-temporal stores: nothing reads them before the finalize pass, and
+            // streaming 134 MB through the L2 only evicts the records still to be folded (C2 step -1.2 %)
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            if ((MASK & 1) && n1) { g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
+                __builtin_nontemporal_store(f4v{g1.x, g1.y, g1.z, g1.w}, reinterpret_cast<f4v*>(pl.sum + cell)); }
+            if ((MASK & 2) && n2) { g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w;
+                __builtin_nontemporal_store(f4v{g2.x, g2.y, g2.z, g2.w}, reinterpret_cast<f4v*>(pl.wgt + cell)); }
             if ((MASK & 4) && n4) { g4.x = fmaxf(g4.x, a4.x); g4.y = fmaxf(g4.y, a4.y); g4.z = fmaxf(g4.z, a4.z); g4.w = fmaxf(g4.w, a4.w); *reinterpret_cast<float4*>(pl.mx + cell) = g4; }
             if ((MASK & 8) && n8) { g8.x = fminf(g8.x, a8.x); g8.y = fminf(g8.y, a8.y); g8.z = fminf(g8.z, a8.z); g8.w = fminf(g8.w, a8.w); *reinterpret_cast<float4*>(pl.mn + cell) = g8; }
         }

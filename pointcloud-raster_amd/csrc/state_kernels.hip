@@ -4,6 +4,8 @@
 // src/engine/pipeline.cpp:1204-1286.  All HBM-streaming, one pass, float4 wide.
 #include "common.hpp"
 
+#include <cstdlib>
+
 using namespace pcrhip;
 
 namespace {
@@ -173,8 +175,11 @@ k_finalize_group(GridDev g, PlanesDev pl, unsigned need, const uint32_t* __restr
             float v[VEC];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) v[k] = live[k] ? finalize_rt(fo.rtype[o], s[k], w[k], mx[k], mn[k]) : NAN;
-            if (VEC == 4) *reinterpret_cast<float4*>(fo.out[o] + oi) = make_float4(v[0], v[1], v[2], v[3]);
-            else fo.out[o][oi] = v[0];
+            if (VEC == 4) {
+                // finished bands: written once, read by nobody on the device (C2 step -1.5 % against plain stores)
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(fo.out[o] + oi));
+            } else fo.out[o][oi] = v[0];
         }
     }
 }
