@@ -1,0 +1,123 @@
+"""Kernel variants that the default benchmark shapes do not reach, against the CPU oracle:
+  * the matrix-core column pass of the moment path (k_conv_col_mfma) on widths that are not a multiple of 4 (scalar staging),
+    odd radii (slack rows), radii that need the 14-round and the unrolled-less staging variants;
+  * the measurement knobs of include/pcr_hip.h (PCR_HIP_TUNE_CONV / _MOM / _REC select alternative kernels that must stay
+    correct: A/B runs quote them).
+Same tolerance as every Gaussian / Line test (rtol 1e-4, exact NaN mask)."""
+import os
+
+import numpy as np
+import pytest
+
+import pcr_oracle_py as O
+from conftest import load_cabi
+from test_gpu_moments import RT, check, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    return load_cabi()
+
+
+class env:
+    """Engine knobs are read when the engine is created: set for the duration of one run."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def gaussian_case(A, G, sigma, maxr, n, tile=(4096, 4096), rname="WeightedAverage", seed=23):
+    W, H = G
+    og = O.make_grid((0.0, 0.0, float(W), float(H)), tile=tile)
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-2.0, W + 2.0, n)
+    y = rng.uniform(-2.0, H + 2.0, n)
+    v = rng.normal(10.0, 3.0, n).astype(np.float32)
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=sigma, sigma_y=sigma, max_radius=maxr)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sigma, sigma_y=sigma, max_radius=maxr)
+    rt = RT[rname]
+    got, st, run = run_gpu(A, og, rt, x, y, v, gl, path=3)
+    run.close()
+    assert st.path == 2, "moment path was not taken"
+    want = O.run(og, rt, x, y, v, glyph=ogl)
+    exact = O.run(og, rt, x, y, v, glyph=ogl, wide=True).astype(np.float64)
+    check(got, want, exact, f"G={G} sigma={sigma} r<={maxr}", scale=1.0 if rname == "Count" else 10.0)
+
+
+MFMA_SHAPES = [
+    dict(id="w203_scalar_staging", G=(203, 150), sigma=8.0, maxr=24.0, n=5000),            # W % 4 != 0
+    dict(id="w1001_scalar_staging_tiles", G=(1001, 96), sigma=8.0, maxr=30.0, n=6000, tile=(300, 64)),
+    dict(id="r25_odd_radius", G=(256, 200), sigma=9.0, maxr=25.0, n=5000),                 # 2r = 2 (mod 4): slack rows
+    dict(id="r27_odd_radius_tiles", G=(300, 260), sigma=9.0, maxr=40.0, n=5000, tile=(128, 100)),
+    dict(id="r60_14_rounds", G=(320, 300), sigma=20.0, maxr=60.0, n=4000),
+    dict(id="r100_loop_staging", G=(420, 400), sigma=34.0, maxr=100.0, n=3000),
+    dict(id="r36_short_window", G=(256, 40), sigma=12.0, maxr=64.0, n=3000),                # window shorter than the tap support
+]
+
+
+@pytest.mark.parametrize("case", MFMA_SHAPES, ids=lambda c: c["id"])
+@pytest.mark.parametrize("rname", ["WeightedAverage", "Count"])
+def test_matrix_core_column_pass_shapes(A, case, rname):
+    gaussian_case(A, case["G"], case["sigma"], case["maxr"], case["n"], tile=case.get("tile", (4096, 4096)), rname=rname)
+
+
+KNOBS = [
+    dict(PCR_HIP_TUNE_CONV=1),      # vector-ALU column pass at a radius the matrix cores would take
+    dict(PCR_HIP_TUNE_CONV=2),      # matrix cores at a radius the vector ALU would take
+    dict(PCR_HIP_TUNE_MOM=2),
+    dict(PCR_HIP_TUNE_MOM=4),
+    dict(PCR_HIP_TUNE_MOM=9),
+]
+
+
+@pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("shape", [dict(G=(300, 230), sigma=16.0, maxr=48.0, n=6000),               # K = 3
+                                   dict(G=(260, 200), sigma=4.0, maxr=12.0, n=8000, tile=(128, 96)),  # K = 5, r = 12
+                                   dict(G=(1301, 90), sigma=8.0, maxr=24.0, n=6000)],                 # K = 4: knobs of K = 3, 5 do not apply
+                         ids=["s16", "s4_tiles", "s8_w1301"])
+def test_measurement_knobs_keep_the_moment_path_exact(A, knob, shape):
+    with env(**knob):
+        gaussian_case(A, shape["G"], shape["sigma"], shape["maxr"], shape["n"], tile=shape.get("tile", (4096, 4096)))
+
+
+def test_rec_scatter_knob_keeps_lines_exact(A):
+    W, H, n = 700, 500, 60000
+    og = O.make_grid((0.0, 0.0, float(W), float(H)))
+    rng = np.random.default_rng(4)
+    x, y = rng.uniform(-3, W + 3, n), rng.uniform(-3, H + 3, n)
+    v = rng.uniform(1.0, 10.0, n).astype(np.float32)         # one sign: the check below is relative
+    d = rng.uniform(0, np.pi, n).astype(np.float32)
+    gl = dict(type=A.GLYPH_LINE, half_length=9.0, max_radius=11.0)
+    ogl = O.make_glyph(O.GLYPH_LINE, half_length=9.0, max_radius=11.0)
+    grid = A.make_grid((0.0, 0.0, float(W), float(H)), dims=(W, H))
+    results = {}
+    for knob in (0, 1):
+        with env(PCR_HIP_TUNE_REC=knob):
+            for rname, mask in (("Count", A.PLANE_WGT), ("Sum", A.PLANE_SUM)):
+                run = A.ReductionRun(grid, mask, path=2)
+                try:
+                    run.scatter(x, y, v, glyph=gl, direction=d)
+                    results[(knob, rname)] = run.finalize(RT[rname])
+                    assert run.stats().path == 1
+                finally:
+                    run.close()
+    want = O.run(og, RT["Count"], x, y, v, glyph=ogl, direction=d)
+    for knob in (0, 1):
+        assert np.array_equal(np.nan_to_num(results[(knob, "Count")], nan=-1.0), np.nan_to_num(want, nan=-1.0)), knob
+    want_s = O.run(og, RT["Sum"], x, y, v, glyph=ogl, direction=d)
+    exact = O.run(og, RT["Sum"], x, y, v, glyph=ogl, direction=d, wide=True).astype(np.float64)
+    for knob in (0, 1):
+        check(results[(knob, "Sum")], want_s, exact, f"line sum knob {knob}", scale=5.0)
