@@ -121,3 +121,43 @@ def test_rec_scatter_knob_keeps_lines_exact(A):
     exact = O.run(og, RT["Sum"], x, y, v, glyph=ogl, direction=d, wide=True).astype(np.float64)
     for knob in (0, 1):
         check(results[(knob, "Sum")], want_s, exact, f"line sum knob {knob}", scale=5.0)
+
+
+def _large_gaussian_case(seed):
+    rng = np.random.default_rng(9000 + seed)
+    W, H = int(rng.integers(60, 700)), int(rng.integers(60, 520))
+    cs = float(rng.choice([0.5, 1.0, 2.0]))
+    tile = (int(rng.choice([96, 200, 257, 4096])), int(rng.choice([80, 128, 301, 4096])))
+    og = O.make_grid((0.0, 0.0, W * cs, H * cs), cell=(cs, -cs), tile=tile)
+    n = int(rng.integers(300, 5000))
+    x = rng.uniform(-3 * cs, og.max_x + 3 * cs, n)
+    y = rng.uniform(-3 * cs, og.max_y + 3 * cs, n)
+    if rng.uniform() < 0.5:                                      # half of the cloud in one blob
+        k = n // 2
+        x[:k] = rng.normal(0.4 * og.max_x, 3 * cs, k)
+        y[:k] = rng.normal(0.5 * og.max_y, 3 * cs, k)
+    v = rng.uniform(1.0, 20.0, n).astype(np.float32)
+    s = float(rng.uniform(8.0, 17.0))
+    sx, sy = s * cs, s * cs * float(rng.choice([1.0, 1.0, 0.9, 1.1]))
+    maxr = float(rng.choice([24.0, 25.0, 31.0, 40.0, 48.0, 64.0]))
+    rname = str(rng.choice(["WeightedAverage", "Sum", "Count"]))
+    return og, x, y, v, sx, sy, maxr, rname
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_large_gaussians_on_the_matrix_core_pass(A, seed):
+    """Random grids, reference tiles, radii 24..51 and widths of any parity through the moment path (r >= 24: k_conv_col_mfma)."""
+    og, x, y, v, sx, sy, maxr, rname = _large_gaussian_case(seed)
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=sx, sigma_y=sy, max_radius=maxr)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sx, sigma_y=sy, max_radius=maxr)
+    rt = RT[rname]
+    try:
+        got, st, run = run_gpu(A, og, rt, x, y, v, gl, path=3)
+    except A.PcrHipError:
+        pytest.skip("expansion not applicable to this spec (cut-off condition)")
+    run.close()
+    assert st.path == 2
+    want = O.run(og, rt, x, y, v, glyph=ogl)
+    exact = O.run(og, rt, x, y, v, glyph=ogl, wide=True).astype(np.float64)
+    check(got, want, exact, f"seed {seed}: {og.width}x{og.height} tile {og.tile_width}x{og.tile_height} "
+          f"sigma {sx:.2f},{sy:.2f} r<={maxr} {rname}", scale=1.0 if rname == "Count" else 10.0)
