@@ -65,6 +65,7 @@ MFMA_SHAPES = [
     dict(id="r60_14_rounds", G=(320, 300), sigma=20.0, maxr=60.0, n=4000),
     dict(id="r100_loop_staging", G=(420, 400), sigma=34.0, maxr=100.0, n=3000),
     dict(id="r36_short_window", G=(256, 40), sigma=12.0, maxr=64.0, n=3000),                # window shorter than the tap support
+    dict(id="r190_largest_lds_image", G=(430, 410), sigma=64.0, maxr=190.0, n=700),         # 464 staged rows: 155 KB of LDS
 ]
 
 
