@@ -252,6 +252,25 @@ def time_steps(pipes, cloud, warmup, world, backend):
     return elapsed, drain(pipes[warmup:]), warm
 
 
+def measured_copy_gbs():
+    """Device-to-device copy bandwidth of THIS box (read + write bytes per second): the practical roof next to the 8 TB/s
+    data-sheet peak (SURVEY section 8d asks for both)."""
+    import torch
+    a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")       # 1 GiB
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(8):
+        b.copy_(a)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / 8
+    del a, b
+    return 2.0 * (1 << 30) / (ms * 1e-3) / 1e9
+
+
 def roofline_of(kernels, info, n, bpp, workload, traffic_db):
     """Dominant kernel by summed HIP-event time; achieved = algorithmic bytes of one launch / its average duration."""
     if not kernels:
@@ -420,6 +439,14 @@ def main():
             out["step_roofline"] = {"algorithmic_bytes": step_bytes,
                                     "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GB/s",
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            if world == 1 and not args.same_device:
+                try:
+                    copy = measured_copy_gbs()
+                    roof["measured_copy_GBps"] = round(copy, 1)
+                    roof["frac_of_measured_copy"] = round(roof["achieved"] / copy, 5)
+                    out["step_roofline"]["frac_of_measured_copy"] = round(out["step_roofline"]["achieved"] / copy, 5)
+                except Exception as exc:                                # informational: never cost the headline
+                    roof["measured_copy_GBps"] = repr(exc)
 
     # ---- the rest of the metric, same run ---------------------------------------------------------
     if not args.no_extras and args.workload is None and not args.host_cloud and not args.host_result:
