@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- Mpts/s of Pipeline.ingest -> finalize on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs either way: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (WORLD_SIZE set:
+this process is a rank), or as plain `python bench.py --gpus N ...` -- then this process only starts that launcher as a
+child (before torch or the GPU are touched), lets rank 0's JSON line through and exits with the child's code.
 
 A step = one ingest + finalize of one synthetic cloud that is already resident in HBM, on a fresh
 pre-created pipeline (the reference's protocol creates the pipeline before the clock,
@@ -10,7 +14,9 @@ scripts/benchmarks/benchmark_glyph_full.py:80-97).  Finalized bands stay in HBM
 
 N = 1 (default): BASELINE.json configs[1] ("C2"): 50 M uniform points, 4096 x 4096 grid, Point glyph,
 Sum + Count + Average on one channel -- the headline `value`.  The same run also reports
-  per_glyph     Line hl=16 / Gaussian sigma = 1, 4, 16 on the same 50 M points and grid (configs[2] settings;
+  per_glyph     Point / Average alone (and with TWO ingests into one pipeline per step: the second ingest read-modify-writes
+                the state planes, the first stores into fresh ones), clustered = configs[3] (10 000 hotspots, Max + Min),
+                Line hl=16 / Gaussian sigma = 1, 4, 16 on the same 50 M points and grid (configs[2] settings;
                 protocol scripts/benchmarks/benchmark_glyph_full.py:92-97,119-133)
   e2e_host      the drop-in default: host-resident cloud in, host-resident result out (PCIe inside the step)
   cpu_baseline  the reference's CPU stages (oracle/pcr_cpu_pipeline.cpp) on this box's host cores,
@@ -22,7 +28,9 @@ reference tiles, so the touched-tile union and -- for Gaussians -- the halo rows
 rank generates, on its device, the 1e9/N points of the cloud that fall in its block (seed 42 + rank): points
 arrive routed by y.  `value` = Point / Average; `per_glyph.gauss1` = Gaussian sigma = 1 (r <= 4) / Average in
 the same run; `one_gpu_same_problem` = the same 1 B points on rank 0's GPU alone (the other ranks wait), so that the line
-carries its own denominator (`speedup_vs_one_gpu`).  --unrouted adds `unrouted`: the same Point step when each rank is
+carries its own denominator (`speedup_vs_one_gpu`).  `selfcheck` (untimed): points valid over all ranks == points
+generated; Gaussian plane sums over all ranks' state rows before the exchange == over the owned rows after it; the
+touched-tile union agrees on every rank -- the first run on a real transport validates its own exchange.  --unrouted adds `unrouted`: the same Point step when each rank is
 instead handed an ARBITRARY 1/N of the cloud and the step includes the device-side partition + all-to-all
 (pcr.distributed.route_cloud).
 --weak keeps round 1's shape (4096 x 4096*N grid, 50 M points per GPU, tile-aligned blocks, no collective).
@@ -35,13 +43,37 @@ import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
-import pcr                        # noqa: E402
-from pcr.distributed import ShardedPipeline, row_block   # noqa: E402
+# torch / pcr are imported by _imports(), AFTER main() has decided whether this process is a rank or only the launcher of
+# the ranks: the launcher must not touch the GPU (it starts `python -m torch.distributed.run` as a child and waits).
+torch = dist = pcr = ShardedPipeline = row_block = None
+
+
+def _imports():
+    global torch, dist, pcr, ShardedPipeline, row_block
+    import torch as _torch
+    import torch.distributed as _dist
+    import pcr as _pcr
+    from pcr.distributed import ShardedPipeline as _SP, row_block as _rb
+    torch, dist, pcr, ShardedPipeline, row_block = _torch, _dist, _pcr, _SP, _rb
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks with torch.distributed.run as a
+    CHILD process (never exec: this process has not touched the GPU and stays that way), let rank 0's JSON line through on
+    the inherited stdout, and return the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PCR_BENCH_SELF_LAUNCHED="1")
+    return subprocess.run(cmd, env=env).returncode
 
 HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 
@@ -59,7 +91,19 @@ WORKLOADS = {
     "C5_point": ("1B uniform pts, 16384^2, Point, Average", "point", ("Average",), 20),
     "C5_gauss1": ("1B uniform pts, 16384^2, Gaussian sigma=1 r<=4, Average", "gauss", 1.0, 20),
 }
-PER_GLYPH = ("line16", "gauss1", "gauss4", "gauss16")
+PER_GLYPH = ("point_avg", "C4", "line16", "gauss1", "gauss4", "gauss16")
+PER_GLYPH_NAME = {"C4": "clustered"}          # key of the leg in the line's per_glyph object
+
+# HBM bytes per point a kernel has to move BY ITS OWN DESIGN (what it reads + what it writes, not the whole path's
+# 20 B/point): the honest numerator for that kernel's own bandwidth, reported as roofline.kernel_own next to the
+# contract's path-level figure.  Point path, C2: profiles/r02_C2_rocprof.md.
+KERNEL_OWN_BYTES_PER_POINT = {
+    "k_bin_count": 20,        # x, y in; 4-byte routing key out
+    "k_bin_scatter": 16,      # key + value in; 8-byte record out
+    "k_tile_accum": 8,        # record in (+ the state planes, per cell)
+    "k_bin16_count": 16,      # x, y in
+    "k_bin16_scatter": 36,    # x, y, value in; 16-byte record out (+ 4 per extra channel)
+}
 
 
 def make_specs(workload):
@@ -171,7 +215,10 @@ def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
     # all cores: every update takes the `omp critical` lock, so with many threads the accumulate stage crawls (measured
     # on the GPU box, 256 threads: 0.06 Mpts/s) -- a much smaller sample keeps the default run short
     all_pts = min(sample_pts, 150_000 if glyph == "point" else 40_000)
-    for label, threads, m in (("1", 1, sample_pts), ("all", ncores, all_pts)):
+    # 8 threads on >= 1 M points: the setting oracle/calibration.json was taken at (the reference's own thread-scaling
+    # table stops at its core count, docs/BENCHMARK_RESULTS.md:52-55)
+    t8_pts = min(sample_pts, 1_000_000 if glyph == "point" else 250_000)
+    for label, threads, m in (("1", 1, sample_pts), ("8", min(8, ncores), t8_pts), ("all", ncores, all_pts)):
         chm = {k: a[:m] for k, a in ch.items()}
         t0 = time.perf_counter()
         for rtype, gl in runs:
@@ -194,6 +241,10 @@ def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
                      f"{out['1'][1]:.1f} s at 1 thread (oracle/pcr_cpu_pipeline.cpp: reference stages incl. its serial sort)",
            "nproc": ncores,
            "stage_seconds_1_thread": {k: round(s, 3) for k, s in stages.get("1", {}).items()}}
+    if "8" in out:
+        res["threads_8"] = {"value": round(out["8"][0], 4), "cores": min(8, ncores), "seconds": round(out["8"][1], 2),
+                            "sample_points": out["8"][2],
+                            "stage_seconds": {k: round(s, 3) for k, s in stages.get("8", {}).items()}}
     if "all" in out:
         res["all_cores"] = {"value": round(out["all"][0], 4), "cores": ncores, "seconds": round(out["all"][1], 2),
                             "sample_points": out["all"][2],
@@ -206,7 +257,7 @@ def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
     return res
 
 
-def time_steps(pipes, cloud, warmup, world, backend):
+def time_steps(pipes, cloud, warmup, world, backend, ingests=1):
     """W untimed + K timed steps of ingest+finalize.  Returns (elapsed seconds MAX over ranks, per-kernel ms of the
     dominant kernel over the TIMED steps, per-kernel ms of every kernel over the WARM-UP steps).
 
@@ -214,7 +265,8 @@ def time_steps(pipes, cloud, warmup, world, backend):
     so the timed steps bracket ONE kernel -- the dominant one, known from the fully bracketed warm-up steps -- and
     otherwise run as they do in production."""
     def step(sp):
-        sp.ingest(cloud)
+        for _ in range(ingests):
+            sp.ingest(cloud)
         sp.finalize()
 
     def drain(sps):
@@ -255,7 +307,6 @@ def time_steps(pipes, cloud, warmup, world, backend):
 def measured_copy_gbs():
     """Device-to-device copy bandwidth of THIS box (read + write bytes per second): the practical roof next to the 8 TB/s
     data-sheet peak (SURVEY section 8d asks for both)."""
-    import torch
     a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")       # 1 GiB
     b = torch.empty_like(a)
     for _ in range(2):
@@ -287,6 +338,14 @@ def roofline_of(kernels, info, n, bpp, workload, traffic_db):
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_kernel_ms": round(avg_ms, 4),
             "algorithmic_bytes_per_launch": bpp * n_launch}
+    # the kernel's OWN bytes (its reads + writes by design; PMC traffic when it was measured on these sources): the
+    # path-level 20 B/point above charges one pass of several with the whole path's input
+    own = KERNEL_OWN_BYTES_PER_POINT.get(dom)
+    own_bytes = traffic if traffic is not None else (own * n_launch if own else None)
+    if own_bytes is not None:
+        own_rate = own_bytes / (avg_ms * 1e-3) / 1e9
+        roof["kernel_own"] = {"bytes_per_launch": own_bytes, "source": "pmc" if traffic is not None else "design",
+                              "achieved": round(own_rate, 2), "frac": round(own_rate / HBM_PEAK_GBS, 5)}
     return roof, dom
 
 
@@ -311,15 +370,17 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N > 1 code path on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the untimed exchange self-check")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the driver's form: plain `python bench.py --gpus N`.  Decided before torch / pcr are imported.
+        sys.exit(self_launch(args.gpus))
+    _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -375,12 +436,13 @@ def main():
         cloud = host_cloud if args.host_cloud else host_cloud.to_device()
         del x, y, v, ch
 
-    def run(wl, steps, warmup, the_cloud=None, cfg_edit=None):
+    def run(wl, steps, warmup, the_cloud=None, cfg_edit=None, ingests=1):
         cfg = make_cfg(wl)
         if cfg_edit:
             cfg_edit(cfg)
         pipes = [ShardedPipeline(cfg, rank, world, device_id=local_rank) for _ in range(warmup + steps)]
-        elapsed, kernels, warm = time_steps(pipes, the_cloud if the_cloud is not None else cloud, warmup, world, args.backend)
+        elapsed, kernels, warm = time_steps(pipes, the_cloud if the_cloud is not None else cloud, warmup, world, args.backend,
+                                            ingests)
         info = pipes[-1].pipe.last_scatter()
         sp = pipes[-1]
         extra = {"halo_rows": sp.halo, "tiles_local": sp.tiles_local,
@@ -395,6 +457,65 @@ def main():
         del pipes
         return elapsed, kernels, info, cfg, extra
 
+    def selfcheck():
+        """N > 1, outside every timed region: the first execution of the exchange on a real transport validates itself.
+        (1) every generated point is valid on exactly one rank: sum over ranks of points_valid == points_total;
+        (2) Gaussian leg: the weight held by ALL ranks' planes (owned rows + halo rows) before the exchange equals the weight
+            in the OWNED rows after it -- nothing lost, nothing counted twice, whatever moved over the wire;
+        (3) the touched-tile union is identical on every rank."""
+        cpu = args.backend != "nccl"
+
+        def allsum(vals, dtype):
+            t = torch.tensor(vals, dtype=dtype, device="cpu" if cpu else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.cpu().tolist()
+
+        res = {}
+        sp = ShardedPipeline(make_cfg(workload), rank, world, device_id=local_rank)
+        sp.ingest(cloud)
+        sp.pipe.synchronize()
+        valid_total, offered_total = allsum([int(sp.pipe.last_scatter()["points_valid"]), int(n)], torch.int64)
+        sp.finalize()
+        res["points_valid_all_ranks"] = int(valid_total)
+        res["points_total"] = int(offered_total)
+        ok = int(valid_total) == int(offered_total)
+        del sp
+
+        spg = ShardedPipeline(make_cfg("C5_gauss1"), rank, world, device_id=local_rank)
+        spg.ingest(cloud)
+        spg.pipe.synchronize()
+        planes = spg._plane_tensors()
+        s0 = spg.pipe.state_row_begin()
+        o0, o1 = spg.own
+        pre = [float(t.double().sum().item()) for t, _ in planes]
+        halo_pre = [float((t.double().sum() - t[o0 - s0:o1 - s0].double().sum()).item()) for t, _ in planes]
+        torch.cuda.synchronize()
+        spg.exchange()
+        spg.pipe.synchronize()
+        torch.cuda.synchronize()
+        post = [float(t[o0 - s0:o1 - s0].double().sum().item()) for t, _ in planes]
+        tot = allsum(pre + post + halo_pre, torch.float64)
+        k = len(planes)
+        pre_t, post_t, halo_t = tot[:k], tot[k:2 * k], tot[2 * k:]
+        rel = [abs(a - b) / max(abs(a), 1e-30) for a, b in zip(pre_t, post_t)]
+        res["gauss_planes"] = k
+        res["gauss_plane_sums_before_exchange"] = [round(v, 3) for v in pre_t]
+        res["gauss_plane_sums_owned_rows_after"] = [round(v, 3) for v in post_t]
+        res["gauss_halo_rows_sum_before_exchange"] = [round(v, 3) for v in halo_t]
+        res["gauss_max_rel_diff"] = max(rel) if rel else 0.0
+        ok = ok and all(r <= 2e-6 for r in rel)          # f32 merges of f32 plane cells, summed in f64
+        if not spg.tiles_local:
+            ok = ok and all(v > 0 for v in halo_t)       # the blocks cut reference tiles: the halo rows DID hold weight
+        touched = spg._touched.to(torch.int64)
+        mine = int(touched.sum().item())
+        t_all = allsum([mine], torch.int64)[0]
+        res["touched_tiles"] = mine
+        ok = ok and t_all == mine * world
+        spg.pipe.finalize()
+        del spg
+        res["ok"] = bool(ok)
+        return res
+
     traffic_db = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -404,6 +525,12 @@ def main():
 
     elapsed, kernels, info, cfg, extra = run(workload, args.steps, args.warmup)
     warm_table = extra.pop("_warm")
+    check = None
+    if strong and not args.no_selfcheck:
+        try:
+            check = selfcheck()
+        except Exception as exc:                                      # a broken check must be visible, not fatal to the line
+            check = {"ok": False, "error": repr(exc)}
 
     out = None
     if rank == 0:
@@ -424,11 +551,15 @@ def main():
                        "input": ("host-resident (H2D inside step)" if args.host_cloud else "device-resident") +
                                 (", pre-routed by y (each rank holds the points of its row block)" if world > 1 else ""),
                        "result": "host (D2H inside step)" if args.host_result else "device-resident",
-                       "parallelism": f"row-block x{world}", "world_size": world,
-                       "backend": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
+                       "parallelism": f"row-block x{world}",
+                       # as the process group itself reports them (nccl IS RCCL on ROCm)
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend())) if world > 1 else None,
                        "state_init": "planes identity-filled at Pipeline.create, outside the clock (~30 us)",
                        **extra},
         }
+        if check is not None:
+            out["selfcheck"] = check
         roof, dom = roofline_of(kernels, info, n, bpp, workload, traffic_db)
         if roof:
             out["roofline"] = roof
@@ -452,21 +583,38 @@ def main():
     if not args.no_extras and args.workload is None and not args.host_cloud and not args.host_result:
         k_extra, w_extra = max(3, min(args.steps, 5)), 2
         per_glyph = {}
-        for wl in (PER_GLYPH if world == 1 else (("C5_gauss1",) if strong else ())):
+        legs = [(wl, 1) for wl in (PER_GLYPH if world == 1 else (("C5_gauss1",) if strong else ()))]
+        if world == 1:
+            legs.insert(1, ("point_avg", 2))       # two ingests into ONE pipeline: the second pays the planes' read-modify-write
+        for wl, ingests in legs:
+            name = PER_GLYPH_NAME.get(wl, wl.replace("C5_", "")) + ("_two_ingests" if ingests > 1 else "")
+            leg_cloud = None
             try:
-                e2, k2, i2, c2, x2 = run(wl, k_extra, w_extra)
+                if wl == "C4":
+                    # BASELINE configs[3]: 10 000 hotspots, offsets N(0, 2 cells) (recipe after
+                    # python/pcr/test_generators.py:560-633), generated on the host, resident before the clock
+                    xc, yc, vc, _ = make_points("C4", n, G, y_lo, y_hi, seed=42 + rank)
+                    leg_cloud = make_cloud(xc, yc, vc, {}).to_device()
+                    del xc, yc, vc
+                e2, k2, i2, c2, x2 = run(wl, k_extra, w_extra, the_cloud=leg_cloud, ingests=ingests)
                 warm2 = x2.pop("_warm")
             except Exception as exc:                                   # a failing leg must not cost the headline
-                per_glyph[wl] = {"error": repr(exc)}
+                per_glyph[name] = {"error": repr(exc)}
                 continue
+            finally:
+                del leg_cloud
             if rank == 0:
                 bpp2 = WORKLOADS[wl][3]
                 roof2, dom2 = roofline_of(k2, i2, n, bpp2, wl, traffic_db)
-                per_glyph[wl.replace("C5_", "")] = {
-                    "workload": WORKLOADS[wl][0], "ms_per_step": round(e2 / k_extra * 1e3, 4),
-                    "Mpts/s": round(n * world * k_extra / e2 / 1e6, 2), "steps": k_extra,
+                step_bytes2 = bpp2 * n * ingests + 4 * G * (r1 - r0) * len(c2.reductions)
+                ms2 = e2 / k_extra * 1e3
+                per_glyph[name] = {
+                    "workload": WORKLOADS[wl][0] + (" -- two ingests of the cloud into one pipeline per step" if ingests > 1 else ""),
+                    "ms_per_step": round(ms2, 4),
+                    "Mpts/s": round(n * ingests * world * k_extra / e2 / 1e6, 2), "steps": k_extra,
                     "scatter_path": i2["path"], "dominant_kernel": dom2,
                     "roofline_frac": roof2["frac"] if roof2 else None,
+                    "step_roofline_frac": round(step_bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "kernels_ms_per_step": warm2,
                     **({"exchange": x2} if world > 1 else {})}
         if rank == 0:

@@ -13,15 +13,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra):
+def _run(extra, launcher=True):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--same-device"] + extra
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"] + extra
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail          # the driver's form: bench.py starts its own ranks as a child process
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -44,6 +49,23 @@ def test_default_multi_gpu_bench_is_c5_strong_scaling_with_live_exchange():
     assert r["unrouted"]["Mpts/s"] > 0
     assert r["one_gpu_same_problem"]["Mpts/s"] > 0 and r["speedup_vs_one_gpu"] > 0
     assert "roofline" in r and r["roofline"]["traffic"] is None or isinstance(r["roofline"]["traffic"], int)
+    _check_selfcheck(r)
+
+
+def _check_selfcheck(r):
+    sc = r["selfcheck"]
+    assert sc["ok"] is True, sc
+    assert sc["points_valid_all_ranks"] == sc["points_total"] == r["config"]["points_total"]
+    assert sc["gauss_planes"] == 2 and sc["gauss_max_rel_diff"] <= 2e-6
+    assert all(v > 0 for v in sc["gauss_halo_rows_sum_before_exchange"])        # the halo rows really carried weight
+    assert r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo"
+
+
+def test_plain_python_bench_gpus_2_launches_its_own_ranks_and_checks_the_exchange():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the driver's form)."""
+    r = _run(["--grid", "6144", "--points", "3000000"], launcher=False)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["value"] > 0
+    _check_selfcheck(r)
 
 
 def test_weak_flag_keeps_round_one_shape_without_collectives():
