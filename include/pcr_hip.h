@@ -249,6 +249,10 @@ int pcr_hip_route_scatter(const uint8_t* d_dest, uint64_t n, int nparts, unsigne
  * row-block shard whose Line glyph has a per-point half_length channel (its y reach is not capped by
  * max_radius_cells: glyph_kernels.cu:228-234). */
 int pcr_hip_absmax_f32(const float* d_values, uint64_t n, float* h_result, pcr_hip_stream s);
+/* The same over the points a filter mask keeps (d_mask may be NULL), with the 4-byte device word the reduction needs
+ * supplied by the caller (NULL: allocated and freed inside, which synchronizes the whole device). */
+int pcr_hip_absmax_f32_masked(const float* d_values, const uint8_t* d_mask, uint64_t n, uint32_t* d_scratch_word,
+                              float* h_result, pcr_hip_stream s);
 
 /* Per-kernel timing with HIP events on the engine's stream (for roofline reporting).
  * While enabled every kernel the engine launches is bracketed by two events; _read drains the

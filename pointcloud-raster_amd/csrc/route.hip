@@ -97,12 +97,12 @@ k_route_scatter(const unsigned char* __restrict__ dest, uint64_t n, int nparts,
 }
 
 __global__ void __launch_bounds__(kThreads)
-k_absmax(const float* __restrict__ v, uint64_t n, unsigned* __restrict__ out_bits) {
+k_absmax(const float* __restrict__ v, const unsigned char* __restrict__ mask, uint64_t n, unsigned* __restrict__ out_bits) {
     float m = 0.f;
     const uint64_t stride = (uint64_t)gridDim.x * kThreads;
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
         const float a = fabsf(v[i]);
-        if (a <= FLT_MAX) m = fmaxf(m, a);                 // skips NaN and inf
+        if (a <= FLT_MAX && (!mask || mask[i])) m = fmaxf(m, a);     // skips NaN, inf and filtered-out points
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -115,23 +115,29 @@ k_absmax(const float* __restrict__ v, uint64_t n, unsigned* __restrict__ out_bit
 extern "C" {
 
 int pcr_hip_absmax_f32(const float* d_values, uint64_t n, float* h_result, pcr_hip_stream s) {
+    return pcr_hip_absmax_f32_masked(d_values, nullptr, n, nullptr, h_result, s);
+}
+
+int pcr_hip_absmax_f32_masked(const float* d_values, const uint8_t* d_mask, uint64_t n, uint32_t* d_scratch_word,
+                              float* h_result, pcr_hip_stream s) {
     PCR_REQUIRE(h_result, "absmax_f32: null result pointer");
     *h_result = 0.f;
     if (n == 0) return PCR_HIP_OK;
     PCR_REQUIRE(d_values, "absmax_f32: null array");
     hipStream_t st = static_cast<hipStream_t>(s);
-    unsigned* d_bits = nullptr;
-    PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bits), sizeof(unsigned)));
+    // a caller that asks on every ingest brings its own device word: hipMalloc + hipFree are device-wide syncs
+    unsigned* d_bits = d_scratch_word;
+    if (!d_bits) PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_bits), sizeof(unsigned)));
     hipError_t err = hipMemsetAsync(d_bits, 0, sizeof(unsigned), st);
     unsigned bits = 0;
     if (err == hipSuccess) {
         const uint64_t want = (n + kThreads - 1) / kThreads;
-        hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(kThreads), 0, st, d_values, n, d_bits);
+        hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(kThreads), 0, st, d_values, d_mask, n, d_bits);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipMemcpyAsync(&bits, d_bits, sizeof bits, hipMemcpyDeviceToHost, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
-    (void)hipFree(d_bits);
+    if (!d_scratch_word) (void)hipFree(d_bits);
     PCR_HIP_TRY(err);
     float f;
     static_assert(sizeof f == sizeof bits, "float bits");

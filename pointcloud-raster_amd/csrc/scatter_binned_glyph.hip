@@ -55,7 +55,10 @@ struct GaussLdsSink {
     int x0, y0, lw, lh;            // window origin in GLOBAL cell coordinates
     __device__ __forceinline__ void add(int row, int col, float vw, float w) {
         int lx = col - x0, ly = row - y0;
-        if ((unsigned)lx < (unsigned)lw && (unsigned)ly < (unsigned)lh) {
+        // A weight that is not in [0, 1] is a NaN (a NaN / inf per-point sigma or rotation: cos(NaN) -> NaN passes the
+        // reference's `w < 1e-6f` test, glyph_kernels.cu:166): the fixed-point plane cannot hold it, so it takes the
+        // float-atomic branch below and reaches the plane as the NaN the reference produces.
+        if ((unsigned)lx < (unsigned)lw && (unsigned)ly < (unsigned)lh && (!(MASK & PCR_HIP_PLANE_WGT) || w <= 1.0f)) {
             int li = ly * lw + lx;
             if (MASK & PCR_HIP_PLANE_SUM) unsafeAtomicAdd(&t_s[li], (double)vw);
             if (MASK & PCR_HIP_PLANE_WGT) atomicAdd(&t_w[li], weight_fix40(w));

@@ -127,6 +127,9 @@ public:
                                // rows never receive anything and need no exchange)
     };
     int halo_rows() const;                       // rows kept above/below the owned block
+    // Row-block shards: rows the Line groups need beyond a centre row for this cloud (0: no check applies).  ingest()
+    // refuses a cloud that needs more than halo_rows(); sharded callers agree on MAX over ranks first.
+    Status line_reach_rows(const PointCloud& cloud, int* rows);
     int state_row_begin() const;
     int state_row_count() const;
     std::vector<PlaneView> state_planes() const;

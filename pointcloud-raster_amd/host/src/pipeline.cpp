@@ -233,21 +233,35 @@ struct Pipeline::Impl {
     // the rounding of the end points), and on north-up grids max_radius_cells does not cap that (hy < 0 passes
     // std::min(h, cap) untouched, glyph_kernels.cu:228-234).  Cells beyond the halo would be clipped by the state
     // window and never reach their owner: refuse instead of returning a grid that differs from the unsharded one.
-    Status check_line_reach(const GlyphSpec& gl, const void* d_half_length, size_t n) {
+    // rows_needed: the reach of the longest segment among the points the filter keeps (0: the check does not apply).
+    Status line_reach_rows(const GlyphSpec& gl, const void* d_half_length, const uint8_t* d_mask, size_t n, int* rows_needed) {
+        *rows_needed = 0;
         if (gl.type != GlyphType::Line || !d_half_length) return Status::success();
         if (own_rows() == hg.height || block_is_whole_tiles()) return Status::success();
+        detail::Buffer& word = staging["line_reach:word"];           // the reduction's device word, kept for the pipeline's life
+        if (word.bytes() < 4) {
+            Status a = word.allocate(256, MemoryLocation::Device);
+            if (!a.ok()) return a;
+        }
         float amax = 0.f;
-        Status s = detail::hip_status(pcr_hip_absmax_f32(static_cast<const float*>(d_half_length), n, &amax, stream));
+        Status s = detail::hip_status(pcr_hip_absmax_f32_masked(static_cast<const float*>(d_half_length), d_mask, n,
+                                                                static_cast<uint32_t*>(word.data()), &amax, stream));
         if (!s.ok()) return s;
-        double rows = std::ceil((double)amax / std::fabs(cfg.grid.cell_size_y)) + 1.0;
+        double rows = std::ceil((double)amax / std::fabs(cfg.grid.cell_size_y));
+        // std::min(h, cap) caps a POSITIVE hy only (south-up grids, cell_size_y > 0): glyph_kernels.cu:228-234
+        if (cfg.grid.cell_size_y > 0) rows = std::min<double>(rows, std::ceil(std::max(gl.max_radius_cells, 0.0f)));
+        rows += 1.0;                                                 // rounding of the end points
         rows = std::min<double>(rows, cfg.grid.tile_height - 1);
-        if (rows > halo)
-            return Status::error(StatusCode::InvalidArgument,
-                "pipeline: a Line segment of this cloud reaches " + std::to_string((long long)rows) +
-                " rows beyond its centre row, but this row-block shard keeps a halo of " + std::to_string(halo) +
-                " rows (sized from default_half_length / max_radius_cells); set PipelineConfig.shard_halo_rows >= " +
-                std::to_string((long long)rows) + " on every rank, or use tile-aligned row blocks");
+        *rows_needed = (int)rows;
         return Status::success();
+    }
+
+    Status reach_error(int rows) const {
+        return Status::error(StatusCode::InvalidArgument,
+            "pipeline: a Line segment of this cloud reaches " + std::to_string((long long)rows) +
+            " rows beyond its centre row, but this row-block shard keeps a halo of " + std::to_string(halo) +
+            " rows (sized from default_half_length / max_radius_cells); set PipelineConfig.shard_halo_rows >= " +
+            std::to_string((long long)rows) + " on every rank, or use tile-aligned row blocks");
     }
 
     // The pipeline's device is made current for the duration of a call that launches or allocates, whatever the
@@ -278,6 +292,30 @@ struct Pipeline::Impl {
         Status s = detail::hip_status(pcr_hip_memcpy_h2d(b.data(), src, bytes, stream));
         if (!s.ok()) return s;
         *out = b.data();
+        return Status::success();
+    }
+
+    // Rows the Line groups of this pipeline need beyond a centre row for THIS cloud (0 when no check applies): what
+    // ingest() would refuse above the shard's halo.  A sharded caller reduces it over the ranks (MAX) first, so that
+    // every rank refuses together instead of one rank raising while the others wait in a collective.  The filter is
+    // not applied here (an upper bound: ingest() itself checks the kept points only).
+    Status query_line_reach(const PointCloud& cloud, int* rows_out) {
+        *rows_out = 0;
+        const size_t n = cloud.count();
+        if (n == 0) return Status::success();
+        DeviceScope dev(cfg.cuda_device_id);
+        for (const auto& gr : groups) {
+            if (gr.glyph.type != GlyphType::Line || gr.glyph.half_length_channel.empty()) continue;
+            const ChannelDesc* d = cloud.channel(gr.glyph.half_length_channel);
+            if (!d || d->dtype != DataType::Float32) continue;
+            const void* hl = nullptr;
+            Status s = device_array(cloud.channel_data(gr.glyph.half_length_channel), cloud.location(), n * sizeof(float),
+                                    "ch:" + gr.glyph.half_length_channel, &hl);
+            if (!s.ok()) return s;
+            int rows = 0;
+            if (!(s = line_reach_rows(gr.glyph, hl, nullptr, n, &rows)).ok()) return s;
+            *rows_out = std::max(*rows_out, rows);
+        }
         return Status::success();
     }
 
@@ -320,12 +358,17 @@ struct Pipeline::Impl {
         s = device_array(cloud.y(), loc, n * sizeof(double), "y", &dy);
         if (!s.ok()) return s;
 
+        std::map<std::string, const void*> staged;      // a channel is staged once per ingest, whoever asks first
         auto f32_channel = [&](const std::string& name, const void** out) -> Status {
             *out = nullptr;
             if (name.empty()) return Status::success();
             const ChannelDesc* d = cloud.channel(name);
             if (!d || d->dtype != DataType::Float32) return Status::success();   // -> GlyphSpec default
-            return device_array(cloud.channel_data(name), loc, n * sizeof(float), "ch:" + name, out);
+            auto hit = staged.find(name);
+            if (hit != staged.end()) { *out = hit->second; return Status::success(); }
+            Status st = device_array(cloud.channel_data(name), loc, n * sizeof(float), "ch:" + name, out);
+            if (st.ok()) staged[name] = *out;
+            return st;
         };
 
         // Filter stage, on the device: a byte mask evaluated once per ingest and honoured by every
@@ -333,6 +376,7 @@ struct Pipeline::Impl {
         // cloud, pipeline.cpp:436-438 vs :662, which is why its own WithFilter test is disabled;
         // here a filtered-out point simply does not exist for any reduction.)
         size_t kept = n;
+        const uint8_t* active_mask = nullptr;
         if (!cfg.filter.empty()) {
             std::vector<pcr_hip_predicate> preds(cfg.filter.predicates.size());
             for (size_t k = 0; k < preds.size(); ++k) {
@@ -361,11 +405,26 @@ struct Pipeline::Impl {
             kept = (size_t)h_count;
             if (kept == 0) return Status::success();             // pipeline.cpp:349-353
             pcr_hip_engine_set_point_mask(engine, d_mask);
+            active_mask = d_mask;
         }
         struct MaskGuard {
             pcr_hip_engine* e;
             ~MaskGuard() { pcr_hip_engine_set_point_mask(e, nullptr); }
         } mask_guard{engine};
+
+        // Row-block shards: every Line group's reach is checked BEFORE the first scatter of this ingest, so a refused
+        // cloud leaves no group half-accumulated (and, sharded, every rank can agree on the verdict first:
+        // Pipeline::line_reach_rows + pcr.distributed.ShardedPipeline.ingest).
+        int reach_needed = 0;
+        for (const auto& gr : groups) {
+            if (gr.glyph.type != GlyphType::Line) continue;
+            const void* hl = nullptr;
+            if (!(s = f32_channel(gr.glyph.half_length_channel, &hl)).ok()) return s;
+            int rows = 0;
+            if (!(s = line_reach_rows(gr.glyph, hl, active_mask, n, &rows)).ok()) return s;
+            reach_needed = std::max(reach_needed, rows);
+        }
+        if (reach_needed > halo) return reach_error(reach_needed);
 
         for (auto& gr : groups) {
             const void* dv = nullptr;
@@ -391,7 +450,6 @@ struct Pipeline::Impl {
                 hgph.d_direction = static_cast<const float*>(p);
                 if (!(s = f32_channel(gr.glyph.half_length_channel, &p)).ok()) return s;
                 hgph.d_half_length = static_cast<const float*>(p);
-                if (!(s = check_line_reach(gr.glyph, p, n)).ok()) return s;
                 if (!(s = f32_channel(gr.glyph.sigma_x_channel, &p)).ok()) return s;
                 hgph.d_sigma_x = static_cast<const float*>(p);
                 if (!(s = f32_channel(gr.glyph.sigma_y_channel, &p)).ok()) return s;
@@ -764,6 +822,7 @@ const Grid* Pipeline::result() const { return impl_->finalized ? impl_->result.g
 ProgressInfo Pipeline::stats() const { return impl_->stats(); }
 
 int Pipeline::halo_rows() const { return impl_->halo; }
+Status Pipeline::line_reach_rows(const PointCloud& cloud, int* rows) { return impl_->query_line_reach(cloud, rows); }
 int Pipeline::state_row_begin() const { return impl_->hg.state_row0; }
 int Pipeline::state_row_count() const { return impl_->hg.state_rows; }
 

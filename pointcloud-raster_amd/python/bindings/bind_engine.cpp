@@ -137,6 +137,11 @@ void bind_engine(py::module_& m) {
              py::arg("dir") = "")
         // extensions for row-block sharded (multi-GPU) runs
         .def("halo_rows", &Pipeline::halo_rows)
+        .def("line_reach_rows", [](Pipeline& p, const PointCloud& cloud) {
+            int rows = 0;
+            raise_if_error(p.line_reach_rows(cloud, &rows));
+            return rows;
+        })
         .def("state_row_begin", &Pipeline::state_row_begin)
         .def("state_row_count", &Pipeline::state_row_count)
         .def("state_planes", [](const Pipeline& p) {

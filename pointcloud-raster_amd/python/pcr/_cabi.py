@@ -90,6 +90,7 @@ SYMBOLS = {
     "pcr_hip_route_count": [C.POINTER(Grid), C.POINTER(C.c_int32), C.c_int, _VP, _VP, _VP, _U64, _VP, _VP, _VP],
     "pcr_hip_route_scatter": [_VP, _U64, C.c_int, _VP, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32), _VP],
     "pcr_hip_absmax_f32": [_VP, _U64, C.POINTER(C.c_float), _VP],
+    "pcr_hip_absmax_f32_masked": [_VP, _VP, _U64, _VP, C.POINTER(C.c_float), _VP],
     "pcr_hip_state_floats": [C.c_int, C.POINTER(C.c_int)],
     "pcr_hip_plane_fill": [_VP, C.c_float, _I64, _VP],
     "pcr_hip_state_init": [C.c_int, _VP, _I64, _VP],

@@ -155,28 +155,34 @@ def partition_cloud(cloud, grid_cfg, blocks, stream=0):
         raise ValueError("partition_cloud: at most 6 channels are routed in one pass")
     ptrs = cloud.device_ptrs()
     dev = torch.device("cuda", torch.cuda.current_device())
-    dest = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    g = _whole_grid(grid_cfg)
-    c_splits = (C.c_int32 * (world + 1))(*splits)
-    A.check(L.pcr_hip_route_count(C.byref(g), c_splits, world, ptrs["x"], ptrs["y"], None, n,
-                                  dest.data_ptr(), counts.data_ptr(), stream))
-    if stream:
-        A.check(L.pcr_hip_stream_synchronize(stream))
-    h_counts = [int(c) for c in counts.cpu().tolist()]            # synchronizes
-    total = sum(h_counts)
-    cursors = torch.tensor([sum(h_counts[:p]) for p in range(world)], dtype=torch.int64, device=dev)
-    grouped = {}
-    srcs, dsts, elems = [], [], []
-    for name in names:
-        t = torch.empty(max(total, 1), dtype=_TORCH_DTYPE[kinds[name]], device=dev)
-        grouped[name] = (t[:total], kinds[name])
-        srcs.append(ptrs[name])
-        dsts.append(t.data_ptr())
-        elems.append(_ELEM_BYTES[kinds[name]])
-    k = len(names)
-    A.check(L.pcr_hip_route_scatter(dest.data_ptr(), n, world, cursors.data_ptr(), k,
-                                    (C.c_void_p * k)(*srcs), (C.c_void_p * k)(*dsts), (C.c_int32 * k)(*elems), stream))
+    # every torch allocation, fill and upload below runs on `stream` too (as torch's current stream), so the kernels
+    # launched on it through the C-ABI are ordered after them whatever stream the caller has current
+    ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream else torch.cuda.stream(torch.cuda.current_stream())
+    with ctx:
+        if not stream:
+            stream = torch.cuda.current_stream().cuda_stream
+        dest = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        g = _whole_grid(grid_cfg)
+        c_splits = (C.c_int32 * (world + 1))(*splits)
+        A.check(L.pcr_hip_route_count(C.byref(g), c_splits, world, ptrs["x"], ptrs["y"], None, n,
+                                      dest.data_ptr(), counts.data_ptr(), stream))
+        h_counts = [int(c) for c in counts.cpu().tolist()]            # D2H on the same stream: synchronizes it
+        total = sum(h_counts)
+        cursors = torch.tensor([sum(h_counts[:p]) for p in range(world)], dtype=torch.int64).to(dev, non_blocking=False)
+        grouped = {}
+        srcs, dsts, elems = [], [], []
+        for name in names:
+            t = torch.empty(max(total, 1), dtype=_TORCH_DTYPE[kinds[name]], device=dev)
+            grouped[name] = (t[:total], kinds[name])
+            srcs.append(ptrs[name])
+            dsts.append(t.data_ptr())
+            elems.append(_ELEM_BYTES[kinds[name]])
+        k = len(names)
+        A.check(L.pcr_hip_route_scatter(dest.data_ptr(), n, world, cursors.data_ptr(), k,
+                                        (C.c_void_p * k)(*srcs), (C.c_void_p * k)(*dsts), (C.c_int32 * k)(*elems), stream))
+        # dest / counts / cursors are released to torch's allocator when this frame ends: safe, because the allocator
+        # reuses a block only on the stream it was allocated on -- this one -- i.e. after the kernels above
     return h_counts, grouped
 
 
@@ -184,6 +190,15 @@ def route_cloud(cloud, grid_cfg, blocks, rank, world, group=None, stream=0):
     """Routes an arbitrary shard of the cloud to the owners of the row blocks: device-side partition, then one
     all-to-all per array (RCCL over xGMI; gloo stages through host memory in rehearsals).  Collective: every rank
     calls it.  Returns a device-resident pcr.PointCloud holding exactly the points whose centre row this rank owns."""
+    import pcr
+    # one stream for the partition kernels, the torch allocations and the collectives (see partition_cloud)
+    ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream else torch.cuda.stream(torch.cuda.current_stream())
+    with ctx:
+        return _route_cloud_on_current_stream(cloud, grid_cfg, blocks, rank, world, group,
+                                              stream or torch.cuda.current_stream().cuda_stream)
+
+
+def _route_cloud_on_current_stream(cloud, grid_cfg, blocks, rank, world, group, stream):
     import pcr
     counts, grouped = partition_cloud(cloud, grid_cfg, blocks, stream)
     stage = dist.get_backend(group) == "gloo"
@@ -235,6 +250,8 @@ class ShardedPipeline:
             raise RuntimeError("Pipeline.create failed: " + pcr.pipeline_create_error())
         self.width = cfg.grid.width
         self.halo = self.pipe.halo_rows()
+        self._line_hl_groups = any(r.glyph.type == pcr.GlyphType.Line and r.glyph.half_length_channel
+                                   for r in cfg.reductions)
         self._views = None
         # Touched flags are per reference tile.  When every block edge falls on a tile-row boundary no tile is
         # shared between ranks and the flags are purely local: a Point-glyph run then needs no collective at all.
@@ -260,7 +277,22 @@ class ShardedPipeline:
 
     def ingest(self, cloud):
         """`cloud` holds (a superset of) the points this rank owns: the engine keeps the points whose centre row is
-        in the owned block and ignores the rest."""
+        in the owned block and ignores the rest.
+
+        A Line group with a per-point half_length channel can need more halo rows than the shard keeps; every rank's
+        need is reduced (MAX) BEFORE anything is accumulated, so that all ranks refuse the round together -- one rank
+        raising alone would leave the others waiting in the next collective."""
+        if self.world > 1 and self._line_hl_groups and not self.tiles_local:
+            need = int(self.pipe.line_reach_rows(cloud))
+            cpu = dist.get_backend(self.group) == "gloo"
+            t = torch.tensor([need], dtype=torch.int32, device="cpu" if cpu else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            need = int(t.item())
+            if need > self.halo:
+                raise RuntimeError(
+                    f"pipeline: a Line segment of this round reaches {need} rows beyond its centre row on some rank, but "
+                    f"the row-block shards keep a halo of {self.halo} rows; set PipelineConfig.shard_halo_rows >= {need} "
+                    "on every rank, or use tile-aligned row blocks (refused on every rank, nothing was accumulated)")
         self.pipe.ingest(cloud)
 
     def _engine_stream(self):

@@ -333,3 +333,34 @@ def test_default_sigma_gaussian_every_small_radius(A, r):
         want = O.run(og, RT[rname], x, y, v, glyph=ogl)
         exact = O.run(og, RT[rname], x, y, v, glyph=ogl, wide=True).astype(np.float64)
         assert_glyph_close(got, want, exact, f"r={r}/{rname}", False)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("rname", ["Count", "WeightedAverage", "Sum"])
+def test_gaussian_nonfinite_rotation_and_sigma_channels(A, rname, path):
+    """A NaN / inf per-point rotation makes every weight of that footprint NaN (cos(NaN); NaN passes the reference's
+    `w < 1e-6f` cut-off, glyph_kernels.cu:166), an inf sigma makes the footprint flat along that axis.  The LDS tiles keep the
+    weight plane in 40-bit fixed point, which cannot hold a NaN: such weights must take the float path and reach the plane as
+    the reference's NaN, not as a large finite number."""
+    og = O.make_grid((0.0, 0.0, 160.0, 120.0), tile=(64, 48))
+    rng = np.random.default_rng(77)
+    n = 3000
+    x, y = rng.uniform(-1.0, 161.0, n), rng.uniform(-1.0, 121.0, n)
+    v = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    rot = rng.uniform(-3.2, 3.2, n).astype(np.float32)
+    bad = rng.choice(n, 24, replace=False)
+    rot[bad[:8]] = np.nan
+    rot[bad[8:12]] = np.inf
+    rot[bad[12:16]] = -np.inf
+    sig = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    sig[bad[16:20]] = np.inf
+    sig[bad[20:]] = np.nan                      # NaN > 0 is false: default sigma
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=1.2, sigma_y=0.9, max_radius=5.0)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=1.2, sigma_y=0.9, max_radius=5.0)
+    ch = dict(rotation=rot, sigma_x=sig)
+    got, st = gpu_run(A, og, RT[rname], [dict(x=x, y=y, value=v, **ch)], glyph=gl, path=path)
+    want = O.run(og, RT[rname], x, y, v, glyph=ogl, **ch)
+    exact = O.run(og, RT[rname], x, y, v, glyph=ogl, wide=True, **ch).astype(np.float64)
+    assert np.isnan(want).sum() > 24                         # the NaN footprints are there
+    assert_glyph_close(got, want, exact, f"nonfinite channels/{rname}/path {path}", False)
+    assert np.isfinite(got[~np.isnan(got)]).all()
