@@ -254,6 +254,34 @@ int pcr_hip_absmax_f32(const float* d_values, uint64_t n, float* h_result, pcr_h
 int pcr_hip_absmax_f32_masked(const float* d_values, const uint8_t* d_mask, uint64_t n, uint32_t* d_scratch_word,
                               float* h_result, pcr_hip_stream s);
 
+/* ---- multi-device: the exchange step of row-block shards, over RCCL / xGMI.  New work: the reference is single-device
+ *      (cuda_device_id, include/pcr/engine/pipeline.h:68); SURVEY section 8b asks for these entry points, 8e fixes their
+ *      shape.  One process per GPU; rank r owns rows [own_row0, own_row1) and keeps `halo` apron rows on each side inside
+ *      its state window [state_row0, state_row0 + state_rows).
+ *        halo_reduce        apron rows -> the neighbour that owns them (ncclSend/ncclRecv to rank +- 1 in one group),
+ *                           merged there with the plane's op (add for SUM / WGT, fmaxf / fminf for MAX / MIN)
+ *        allreduce_max_u32  the touched-tile flags (one word per reference tile)
+ *      Both are enqueued on the caller's stream.  RCCL is loaded on first use (librccl.so.1); without it the calls
+ *      return PCR_HIP_NOT_IMPLEMENTED and pcr_hip_comm_available() is 0.  Bootstrap: rank 0 makes a 128-byte id, the
+ *      host carries it to the other ranks (MPI, a file, torch.distributed, ...), every rank calls _create. */
+#define PCR_HIP_COMM_ID_BYTES 128
+typedef struct pcr_hip_comm pcr_hip_comm;
+typedef struct pcr_hip_halo_plane {
+    float* d_plane;            /* state_rows x width floats */
+    uint32_t kind;             /* PCR_HIP_PLANE_SUM / _WGT / _MAX / _MIN */
+    uint32_t reserved_;
+} pcr_hip_halo_plane;
+int pcr_hip_comm_available(void);
+int pcr_hip_comm_unique_id(uint8_t* id128);
+int pcr_hip_comm_create(pcr_hip_comm** out, const uint8_t* id128, int rank, int world, int device);
+int pcr_hip_comm_destroy(pcr_hip_comm* c);
+int pcr_hip_comm_rank(const pcr_hip_comm* c, int* rank, int* world);
+int pcr_hip_comm_halo_reduce(pcr_hip_comm* c, const pcr_hip_halo_plane* planes, int nplanes, int width,
+                             int state_row0, int state_rows, int own_row0, int own_row1, int halo, pcr_hip_stream s);
+int pcr_hip_comm_allreduce_max_u32(pcr_hip_comm* c, uint32_t* d_words, int count, pcr_hip_stream s);
+int pcr_hip_comm_allreduce_sum_f64(pcr_hip_comm* c, double* d_values, int count, pcr_hip_stream s);
+int pcr_hip_comm_stats(const pcr_hip_comm* c, uint64_t* halo_reduces, uint64_t* bytes_sent);
+
 /* Per-kernel timing with HIP events on the engine's stream (for roofline reporting).
  * While enabled every kernel the engine launches is bracketed by two events; _read drains the
  * events (synchronizes) and returns, per kernel name, launches and summed milliseconds. */

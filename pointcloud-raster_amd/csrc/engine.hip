@@ -184,6 +184,8 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
     }
     if (const char* dbg = std::getenv("PCR_HIP_DEBUG_TWO_LEVEL")) e->two_level = std::atoi(dbg) != 0;
     if (const char* t = std::getenv("PCR_HIP_ONE_PASS")) e->one_pass = std::atoi(t) != 0;
+    if (const char* t = std::getenv("PCR_HIP_CELL_TILES")) e->cell_tiles = std::atoi(t) != 0;
+    if (const char* t = std::getenv("PCR_HIP_B16_THREADS")) e->b16_threads = std::atoi(t);
     if (const char* t = std::getenv("PCR_HIP_TUNE_SCATTER")) e->tune_scatter = std::atoi(t);
     if (const char* t = std::getenv("PCR_HIP_TUNE_B")) e->tune_b = std::atoi(t);
     if (const char* t = std::getenv("PCR_HIP_TUNE_MOM")) e->tune_mom = std::atoi(t);
@@ -394,7 +396,8 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: binned path forced but not applicable");
     if (e->forced_path == 1 || !can_bin) return direct_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
-    rc = binned_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    if (e->cell_tiles && cells_gauss_supported(e, gl, plane_mask)) rc = cells_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    else rc = binned_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
     release_scratch(e);
     return rc;
 }

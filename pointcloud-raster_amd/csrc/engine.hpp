@@ -28,6 +28,8 @@ struct pcr_hip_engine {
     int tune_b = 0;                            // PCR_HIP_TUNE_B=1: print k_bin_scatter's phase cycles (experiments only; synchronizes)
     bool one_pass = false;                     // PCR_HIP_ONE_PASS=1: sampled-provisioning one-pass sort for the Point glyph (opt-in)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
+    int b16_threads = 512;                     // PCR_HIP_B16_THREADS: workgroup size of the 16-byte-record scatter pass (experiments)
+    bool cell_tiles = true;                    // PCR_HIP_CELL_TILES=0: small Gaussians on round 2's index-record tiles (A/B runs)
     pcr_hip_scatter_stats stats{};
     bool planes_fresh = false;                 // pcr_hip_engine_planes_fresh: the NEXT scatter's planes hold identity values
 
@@ -138,6 +140,11 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
 bool binned_glyph_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);
 int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
                  const double* x, const double* y, const float* v, uint64_t n);
+
+// Gaussian cell tiles on 16-byte value records (default-sigma, unrotated, r <= 3), scatter_cells.hip
+bool cells_gauss_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);
+int cells_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
+                const double* x, const double* y, const float* v, uint64_t n);
 
 // separable moment + convolution path for large default-sigma Gaussians, scatter_moments.hip
 bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);

@@ -13,8 +13,7 @@
 //
 // Replaces kernel_glyph_gaussian / kernel_glyph_line (src/engine/glyph_kernels.cu:345-492);
 // arithmetic follows the CPU reference (glyph_device.hpp).
-#include "engine.hpp"
-#include "glyph_device.hpp"
+#include "bin16.hpp"
 
 #include <cstdlib>
 
@@ -208,6 +207,125 @@ k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const GlyphRec* _
     }
 }
 
+// ---- Line tiles on 16-byte records (bin16.hpp) -----------------------------------------------------------------
+// Round 2 carried x, y, value and the per-point channels to the tile in 32-byte records and did the end-point
+// arithmetic (an f64 sincos per segment) there.  The scatter pass of the shared front-end has x, y and the channels in
+// registers anyway: it computes the segment's rounded END POINTS (glyph_kernels.cu:213-250) and stores
+//     {local centre cell, value, (ix0, iy0), (ix1, iy1)}      end points as int16 offsets from the tile's origin
+// -- half the record bytes both ways, and the tile kernel is left with the integer walk.  The clip rectangle (the
+// centre cell's reference tile, Q4) follows from the centre cell.  A segment whose end points do not fit an int16
+// offset (a garbage half_length: |offset| > 32000 cells) goes to the list and is walked by the direct form.
+struct LineRecMaker {
+    static constexpr bool kCentre = false;
+    static constexpr int kPer = 12;                           // the f64 sincos of the end points needs the registers
+    GlyphDev gl;
+    struct Chan { float dir, hl; };
+    __device__ __forceinline__ Chan load(uint64_t i) const {
+        Chan c{0.f, 0.f};
+        if (gl.direction) c.dir = gl.direction[i];
+        if (gl.half_length) c.hl = gl.half_length[i];
+        return c;
+    }
+    __device__ __forceinline__ bool make(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
+                                         float val, const Chan& ch, uint4& rec) const {
+        const LineParams q = line_params(g, gl, pg, val, GlyphChan{ch.dir, ch.hl, 0.f});
+        const int by = r.bin / b.bins_x, bx = r.bin - by * b.bins_x;
+        const long long ox = (long long)bx * b.tile_w, oy = (long long)g.st_r0 + b.row0 + (long long)by * b.tile_h;
+        const long long a0 = q.ix0 - ox, b0 = q.iy0 - oy, a1 = q.ix1 - ox, b1 = q.iy1 - oy;
+        const long long lim = 32000;
+        if (a0 < -lim || a0 > lim || b0 < -lim || b0 > lim || a1 < -lim || a1 > lim || b1 < -lim || b1 > lim) return false;
+        rec.y = __float_as_uint(val);
+        rec.z = ((unsigned)a0 & 0xFFFFu) | ((unsigned)b0 << 16);
+        rec.w = ((unsigned)a1 & 0xFFFFu) | ((unsigned)b1 << 16);
+        return true;
+    }
+};
+
+template <unsigned MASK, bool COVERED>
+__global__ void __launch_bounds__(kThreads)
+k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ records,
+              const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
+    extern __shared__ double lds_win[];
+    if (blockIdx.x >= *n_items) return;
+    const BinItem it = items[blockIdx.x];
+    const int cells = t.lw * t.lh;                           // even (lw, lh even)
+    double* t_s = lds_win;
+    unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
+    // the first records are in flight while the window is cleared
+    const uint4* rec = records + it.first;
+    uint4 cur = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        if (MASK & 1) t_s[i] = 0.0;
+        if (MASK & 2) t_c[i] = 0u;
+    }
+    __syncthreads();
+
+    const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
+    const int ox = bx * t.bins.tile_w, oy = g.st_r0 + t.bins.row0 + by * t.bins.tile_h;      // the tile's origin, global cells
+    LineLdsSink<MASK, COVERED> sink{g, pl, t_s, t_c, ox - t.apron, oy - t.apron, t.lw, t.lh};
+    // every wave runs the same number of rounds (the walk below is wave-cooperative: shuffles inside)
+    for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
+        const unsigned jn = j0 + kThreads + threadIdx.x;
+        const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+        const bool valid = cur.x != b16::kNullCell;
+        LineParams q{};
+        if (valid) {
+            const int ly = fast_div((int)cur.x, t.bins.tile_w), lx = (int)cur.x - ly * t.bins.tile_w;
+            const int col = ox + lx, row = oy + ly;                      // the centre cell: its reference tile clips (Q4)
+            const int tcx = fast_div(col, g.tw), tcy = fast_div(row, g.th);
+            q.cx0 = tcx * g.tw;
+            q.cx1 = min(q.cx0 + g.tw, g.W);
+            q.cy0 = max(tcy * g.th, g.st_r0);
+            q.cy1 = min(min(tcy * g.th + g.th, g.H), g.st_r0 + g.st_rows);
+            q.val = __uint_as_float(cur.y);
+            q.ix0 = ox + (int)(short)(cur.z & 0xFFFFu);
+            q.iy0 = oy + (int)(short)(cur.z >> 16);
+            q.ix1 = ox + (int)(short)(cur.w & 0xFFFFu);
+            q.iy1 = oy + (int)(short)(cur.w >> 16);
+        }
+        line_walk_wave(q, valid, sink);
+        cur = nxt;
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        double s = (MASK & 1) ? t_s[i] : 0.0;
+        unsigned c = (MASK & 2) ? t_c[i] : 0u;
+        if (s == 0.0 && c == 0u) continue;
+        int ly = i / t.lw, lx = i - ly * t.lw;
+        int64_t cell = (int64_t)(sink.y0 + ly - g.st_r0) * g.W + (sink.x0 + lx);
+        if ((MASK & 1) && s != 0.0) atomic_add_f32(pl.sum + cell, (float)s);
+        if ((MASK & 2) && c) atomic_add_f32(pl.wgt + cell, (float)c);
+    }
+}
+
+// the listed segments: one lane walks one segment straight into the planes
+template <unsigned MASK>
+struct LineDirectSink {
+    const GridDev& g;
+    PlanesDev pl;
+    __device__ __forceinline__ void add(int row, int col, float vw, float) {
+        const int64_t cell = (int64_t)(row - g.st_r0) * g.W + col;
+        if (MASK & 1) atomic_add_f32(pl.sum + cell, vw);
+        if (MASK & 2) atomic_add_f32(pl.wgt + cell, 1.0f);
+    }
+};
+
+template <unsigned MASK>
+__global__ void __launch_bounds__(256)
+k_line_list(GridDev g, GlyphDev gl, PlanesDev pl, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
+            const double* __restrict__ x, const double* __restrict__ y, const float* __restrict__ v) {
+    const unsigned n = *count;
+    LineDirectSink<MASK> sink{g, pl};
+    for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const uint64_t i = list[j];
+        PointGeom pg = point_geom(g, x[i], y[i]);
+        if (!pg.valid) continue;
+        const LineParams q = line_params(g, gl, pg, v[i], load_chan(gl, i));
+        line_walk(q, sink);
+    }
+}
+
 // ---- host: tile geometry from the glyph spec ---------------------------------------------------------
 int apron_needed(const GridDev& g, const GlyphDev& gl) {
     double cap = std::min<double>(std::max(gl.max_radius, 0.0f), 4096.0);
@@ -356,6 +474,60 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
             e->stats.num_bins = t.bins.nbins;
             return PCR_HIP_OK;
         }
+    }
+    if (gl.type == PCR_HIP_GLYPH_LINE && e->cell_tiles) {
+        // 16-byte end-point records through the shared front-end (bin16.hpp); bands as below
+        const int band16 = band_rows_for(e->gd, S, S, b16::max_bins(e));
+        if (band16 <= 0) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: grid cannot be binned");
+        const int max_bins = t.bins.bins_x * ((std::min(band16, e->gd.st_rows) + S - 1) / S);
+        const b16::Layout L = b16::layout(0, max_bins, n, item_points);
+        int rc = ensure_scratch(e, L.end);
+        if (rc) return rc;
+        PCR_HIP_TRY(hipMemsetAsync(e->d_scratch + L.o_fbc, 0, 4, e->stream));
+        const bool covered = t.apron >= t.need && !gl.half_length;
+        for (int row0 = 0; row0 < e->gd.st_rows; row0 += band16) {
+            const int rows = std::min(band16, e->gd.st_rows - row0);
+            GridDev gd = e->gd;
+            gd.own_r0 = std::max(e->gd.own_r0, e->gd.st_r0 + row0);
+            gd.own_r1 = std::min(e->gd.own_r1, e->gd.st_r0 + row0 + rows);
+            if (gd.own_r0 >= gd.own_r1) continue;
+            t.bins.row0 = row0;
+            t.bins.rows = rows;
+            t.bins.bins_y = (rows + S - 1) / S;
+            t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
+            t.bins.chunk = b16::chunk_of<LineRecMaker>(e);
+            total_bins += t.bins.nbins;
+            b16::Buffers bb{};
+            rc = b16::bin(e, gd, t.bins, LineRecMaker{gl}, x, y, v, n, item_points, L, &bb);
+            if (rc) return rc;
+            ScopedKernelTimer tm(e, "k_tile_line");
+            auto go = [&](auto kernel) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, t, pl, bb.records, bb.items, bb.n_items);
+            };
+#define PCR_LINE16(M) if (covered) go(&k_tile_line16<M, true>); else go(&k_tile_line16<M, false>);
+            switch (mask) {
+                case 1: PCR_LINE16(1) break;
+                case 2: PCR_LINE16(2) break;
+                default: PCR_LINE16(3) break;
+            }
+#undef PCR_LINE16
+        }
+        {
+            ScopedKernelTimer tm(e, "k_line_list");                // normally an empty list
+            unsigned* d_fbl = reinterpret_cast<unsigned*>(e->d_scratch + L.o_fbl);
+            unsigned* d_fbc = reinterpret_cast<unsigned*>(e->d_scratch + L.o_fbc);
+            if (mask == 1) hipLaunchKernelGGL(k_line_list<1>, dim3(64), dim3(256), 0, e->stream, e->gd, gl, pl, d_fbl, d_fbc, x, y, v);
+            else if (mask == 2) hipLaunchKernelGGL(k_line_list<2>, dim3(64), dim3(256), 0, e->stream, e->gd, gl, pl, d_fbl, d_fbc, x, y, v);
+            else hipLaunchKernelGGL(k_line_list<3>, dim3(64), dim3(256), 0, e->stream, e->gd, gl, pl, d_fbl, d_fbc, x, y, v);
+        }
+        PCR_HIP_TRY(hipGetLastError());
+        e->stats.path = 1;
+        e->stats.lds_tile_w = t.bins.tile_w;
+        e->stats.lds_tile_h = t.bins.tile_h;
+        e->stats.lds_apron = t.apron;
+        e->stats.num_bins = total_bins;
+        return PCR_HIP_OK;
     }
     // row bands: a band bins the points whose CENTRE row it holds; footprints reach into neighbouring
     // bands through the apron / global-atomic spill exactly as they reach into neighbouring tiles

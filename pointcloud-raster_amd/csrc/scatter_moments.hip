@@ -25,8 +25,7 @@
 // Work per point drops from (2r+1)^2 weighted atomics (9409 at sigma=16) to ~P multiply-adds.
 // Points the expansion cannot represent (non-finite value, centre cell not the routed cell at a
 // grid edge) are painted by the wave-per-point direct kernel afterwards.
-#include "engine.hpp"
-#include "glyph_device.hpp"
+#include "bin16.hpp"
 
 #include <type_traits>
 #include <vector>
@@ -35,11 +34,10 @@ using namespace pcrhip;
 
 namespace {
 
-constexpr int kThreads = 1024;        // count / scatter passes
-constexpr int kMomThreads = 512;      // per-tile moment reduction (register heavy)
+constexpr int kMomThreads = 256;      // per-tile moment reduction: four waves, three workgroups per CU
 constexpr int kPad = 20;              // zero padding of the tap tables (16-output windows, 4 source rows per step)
-constexpr int kTileW = 128, kTileH = 72;                 // 9216 cells: two u32 tables + index list fit the LDS
-constexpr int kSortChunk = 32768;                        // records sorted per round inside LDS (u16 positions: 64 KB)
+constexpr int kTileW = 64, kTileH = 16;                  // a wave folds one row of the tile at a time; ~3 K records staged in LDS
+constexpr int kSortChunk = 4096;                         // records staged per round (48 KB of LDS)
 constexpr int kMaxK = 9;
 constexpr double kTruncationBound = 5e-5;      // make_plan: rigorous bound on the relative error of any weight
 
@@ -52,386 +50,139 @@ struct MomPlan {
 
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u; }
 
-// ---- pass A: eligibility + histogram -----------------------------------------------------------------
-// 512-thread workgroups, like k_bin_count: the kernel is SGPR-limited to 7 waves per SIMD, so 1024-thread groups ran one
-// per CU; three groups of 512 keep half as many loads again in flight.
-constexpr int kMomCountThreads = 512;
+// ---- binning: the shared front-end (bin16.hpp) on records {local cell, value, s'x, s'y} -----------------------
+// s' = the reference's f32 sub-cell offset, recentred to [-1/2, 1/2).  A point whose value is not finite, or whose
+// centre cell is not the routed cell (grid edge), cannot be represented by moments: it goes to the list.
+struct MomentMaker {
+    static constexpr bool kCentre = true;
+    static constexpr int kPer = 16;
+    struct Chan {};
+    __device__ __forceinline__ Chan load(uint64_t) const { return Chan{}; }
+    __device__ __forceinline__ bool make(const GridDev&, const BinGeom&, const b16::Routed16&, const PointGeom& pg, float val,
+                                         const Chan&, uint4& rec) const {
+        if (!finite_f(val)) return false;
+        rec.y = __float_as_uint(val);
+        rec.z = __float_as_uint((float)(pg.fcx - floor(pg.fcx)) - 0.5f);
+        rec.w = __float_as_uint((float)(pg.fcy - floor(pg.fcy)) - 0.5f);
+        return true;
+    }
+};
 
-__global__ void __launch_bounds__(kMomCountThreads)
-k_mom_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
-            const float* __restrict__ v, uint64_t n, unsigned* __restrict__ keys,
-            unsigned* __restrict__ bin_count, unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count,
-            uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
-    extern __shared__ unsigned lds_hist[];
-    for (int i = threadIdx.x; i < b.nbins; i += kMomCountThreads) lds_hist[i] = 0;
-    __shared__ unsigned any_valid;
-    if (threadIdx.x == 0) any_valid = 0;
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
-    const bool one_tile = g.tiles_x * g.tiles_y == 1;
-    unsigned my_valid = 0;
-    auto handle = [&](uint64_t i, double wx, double wy, float val) -> unsigned {
-        PointGeom pg = point_geom(g, wx, wy);
-        if (!(pg.valid && point_kept(g, i))) return 0xFFFFFFFFu;
-        ++my_valid;
-        if (!one_tile) touch_tile(g, touched, pg.row, pg.col);      // one reference tile: flagged once per block below
-        int icx = (int)floor(pg.fcx), icy = (int)floor(pg.fcy);
-        if (finite_f(val) && icx == pg.col && icy == pg.row) {
-            int sr = pg.row - g.st_r0 - b.row0;                    // row inside the band the bins cover
-            int bx = fast_div(pg.col, b.tile_w), by = fast_div(sr, b.tile_h);
-            int bin = by * b.bins_x + bx;
-            atomicAdd(&lds_hist[bin], 1u);
-            return ((unsigned)bin << kLcellBits) | (unsigned)((sr - by * b.tile_h) * b.tile_w + (pg.col - bx * b.tile_w));
-        }
-        fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;                   // rare: painted directly afterwards
-        return 0xFFFFFFFFu;
-    };
-    const bool full = base + (uint64_t)b.chunk <= n &&
-                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
-                      (reinterpret_cast<uintptr_t>(v) & 7) == 0;
-    if (full) {
-        // two points per lane and load, four loads per array in flight before any math
-        const double2* x2 = reinterpret_cast<const double2*>(x + base);
-        const double2* y2 = reinterpret_cast<const double2*>(y + base);
-        const float2* v2 = reinterpret_cast<const float2*>(v + base);
-        uint2* k2 = reinterpret_cast<uint2*>(keys + base);
-        const int pairs = b.chunk >> 1;                          // 4096 or 2048 pairs: one trip, 4 or 2 loads per array
-        for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kMomCountThreads) {
-            double2 xs[4], ys[4];
-            float2 vs[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (p0 + u * kMomCountThreads >= pairs) break;           // uniform
-                xs[u] = x2[p0 + u * kMomCountThreads];
-                ys[u] = y2[p0 + u * kMomCountThreads];
-                vs[u] = v2[p0 + u * kMomCountThreads];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (p0 + u * kMomCountThreads >= pairs) break;
-                const uint64_t i = base + 2ull * (p0 + u * kMomCountThreads);
-                unsigned ka = handle(i, xs[u].x, ys[u].x, vs[u].x);
-                unsigned kb = handle(i + 1, xs[u].y, ys[u].y, vs[u].y);
-                k2[p0 + u * kMomCountThreads] = make_uint2(ka, kb);
-            }
-        }
-    } else {
-        for (int k = threadIdx.x; k < b.chunk; k += kMomCountThreads) {
-            uint64_t i = base + k;
-            if (i >= n) break;
-            keys[i] = handle(i, x[i], y[i], v[i]);
-        }
-    }
-    if (my_valid) atomicAdd(&any_valid, my_valid);
-    __syncthreads();
-    for (int i = threadIdx.x; i < b.nbins; i += kMomCountThreads) {
-        unsigned c = lds_hist[i];
-        if (c) atomicAdd(&bin_count[i], c);
-    }
-    if (threadIdx.x == 0 && any_valid) {
-        atomicAdd(counters, (unsigned long long)any_valid);
-        if (one_tile) touched[0] = 1u;
-    }
-}
-
-// bin starts (no work items: one workgroup per bin, empty bins included so that every moment
-// cell is written and no memset of the planes is needed)
-__global__ void __launch_bounds__(kThreads)
-k_mom_scan(int nbins, const unsigned* __restrict__ bin_count, unsigned* __restrict__ bin_start,
-           unsigned* __restrict__ cursor) {
-    __shared__ unsigned part[kThreads];
-    const int per = (nbins + kThreads - 1) / kThreads;
-    const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
-    unsigned s = 0;
-    for (int i = lo; i < hi; ++i) s += bin_count[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        unsigned a = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += a;
-        __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; ++i) {
-        bin_start[i] = run;
-        cursor[i] = run;
-        run += bin_count[i];
-    }
-    if (threadIdx.x == kThreads - 1) bin_start[nbins] = part[threadIdx.x];
-}
-
-// ---- pass B: 16-byte records {local cell, value, s'x, s'y}, grouped by bin ---------------------------
-// points per thread: 8 (8192-point chunks, 128 KB of staging, up to 2560 tiles) or 4 (4096-point chunks, up to 8064 tiles)
-
-template <int kScatterPer>
-__global__ void __launch_bounds__(kThreads)
-k_mom_scatter(GridDev g, BinGeom b, const unsigned* __restrict__ keys, const double* __restrict__ x,
-              const double* __restrict__ y, const float* __restrict__ v, uint64_t n,
-              unsigned* __restrict__ cursor, uint4* __restrict__ records) {
-    extern __shared__ unsigned char lds_raw[];
-    uint4* stage = reinterpret_cast<uint4*>(lds_raw);
-    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)b.chunk * sizeof(uint4));
-    unsigned* loff = hist + b.nbins;
-    unsigned* gbase = loff + b.nbins;
-    __shared__ unsigned wave_tot[kThreads / 64];
-    for (int i = threadIdx.x; i < b.nbins; i += kThreads) hist[i] = 0;
-    __syncthreads();
-
-    const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
-    unsigned key[kScatterPer], rank[kScatterPer];
-    float val[kScatterPer], sx[kScatterPer], sy[kScatterPer];
-    {
-        // every load of the chunk is issued before the first use (a point that will be dropped is read too)
-        double wx[kScatterPer], wy[kScatterPer];
-#pragma unroll
-        for (int k = 0; k < kScatterPer; ++k) {
-            const uint64_t i = base + (uint64_t)k * kThreads + threadIdx.x;
-            const uint64_t ic = i < n ? i : n - 1;
-            key[k] = i < n ? keys[ic] : 0xFFFFFFFFu;
-            wx[k] = x[ic];
-            wy[k] = y[ic];
-            val[k] = v[ic];
-        }
-#pragma unroll
-        for (int k = 0; k < kScatterPer; ++k) {
-            rank[k] = 0;
-            sx[k] = sy[k] = 0.f;
-            if (key[k] != 0xFFFFFFFFu) {
-                double fcx = (wx[k] - g.min_x) * g.inv_csx, fcy = (wy[k] - g.max_y) * g.inv_csy;
-                sx[k] = (float)(fcx - floor(fcx)) - 0.5f;        // the reference's f32 sub-cell offset, recentred
-                sy[k] = (float)(fcy - floor(fcy)) - 0.5f;
-                rank[k] = atomicAdd(&hist[key[k] >> kLcellBits], 1u);
-            } else {
-                val[k] = 0.f;
-            }
-        }
-    }
-    __syncthreads();
-    const int per = (b.nbins + kThreads - 1) / kThreads;
-    const int lo = threadIdx.x * per, hi = min(lo + per, b.nbins);
-    unsigned s = 0;
-    for (int i = lo; i < hi; ++i) s += hist[i];
-    unsigned incl = s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
-    unsigned run = wave_base + incl - s;
-    for (int i = lo; i < hi; ++i) {
-        loff[i] = run;
-        run += hist[i];
-    }
-    unsigned total = 0;
-    for (int w = 0; w < kThreads / 64; ++w) total += wave_tot[w];
-    __syncthreads();
-    // reservations: bins dealt to lanes interleaved (a wave's atomics hit 64 consecutive words), issued back to back
-    {
-        constexpr int kRes = 4;
-        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * kThreads) {
-            unsigned c[kRes], gp[kRes];
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                const int i = i0 + u * kThreads;
-                c[u] = i < b.nbins ? hist[i] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                gp[u] = 0;
-                if (c[u]) gp[u] = atomicAdd(&cursor[i0 + u * kThreads], c[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < kRes; ++u)
-                if (c[u]) gbase[i0 + u * kThreads] = gp[u];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < kScatterPer; ++k)
-        if (key[k] != 0xFFFFFFFFu)
-            stage[loff[key[k] >> kLcellBits] + rank[k]] =
-                make_uint4(key[k], __float_as_uint(val[k]), __float_as_uint(sx[k]), __float_as_uint(sy[k]));
-    __syncthreads();
-    for (unsigned j = threadIdx.x; j < total; j += kThreads) {
-        uint4 rec = stage[j];
-        unsigned bin = rec.x >> kLcellBits;
-        rec.x &= (1u << kLcellBits) - 1;
-        records[gbase[bin] + (j - loff[bin])] = rec;
-    }
-}
-
-// ---- pass C: per-tile moments: sort the bin's records by cell in LDS, reduce per cell in registers ----
-// A bin (128 x 72 cells, ~27 K records = 442 KB) is shared by kMomSplit = 4 workgroups, each owning 18 of its 72 rows.
-// The reduction fetches a cell's records by their sorted position -- random 16-byte reads inside the bin's record
-// range.  With one workgroup per bin the 32 CUs of an XCD worked on 32 bins (14 MB of records against 4 MB of L2) and
-// every gathered record cost a whole 128-byte line from HBM: 5.7 GB fetched for 0.8 GB of records, the kernel ran at
-// the fetch bandwidth (profiles/r02_gauss16_rocprof.md).  The four workgroups of a bin get consecutive dispatch slots
-// on ONE XCD (workgroups go to the XCDs round-robin: blockIdx = (slot * 8 + xcd)), so an XCD holds 8 bins = 3.5 MB at a
-// time and the gathers hit its L2; every workgroup streams the whole bin's cell indices (L2 hits for three of the
-// four) and keeps the records of its own rows.
-template <int K, unsigned MASK, int kMomSplit, bool NT>
+// ---- per-tile moments: the tile's records are sorted by cell INSIDE LDS (the records themselves are staged, 12
+// bytes each), then a lane owns a cell and folds its records into P (x2) moments held in registers -- no atomics
+// on the moments, and no second trip to memory: round 2 kept only 16-bit positions in LDS and gathered the 16-byte
+// records by position, 128-byte lines for 16 useful bytes (5.5 GB fetched for 0.8 GB of records,
+// profiles/r02_moments_split.md).  Tiles are 64 x 16 cells so that a tile's ~3 K records fit three workgroups per CU;
+// a crowded tile is folded in rounds of kSortChunk records.  One workgroup per tile, empty tiles included, so that
+// every moment cell is written and the planes need no memset.
+template <int K, unsigned MASK, bool NT>
 __global__ void __launch_bounds__(kMomThreads)
 k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* __restrict__ records,
                const unsigned* __restrict__ bin_start, float* __restrict__ mom_v, float* __restrict__ mom_w,
                int64_t plane_stride) {
     constexpr int P = (K + 1) * (K + 2) / 2;
-    constexpr int kPartRows = kTileH / kMomSplit, kPartCells = kTileW * kPartRows;       // split 4: 18 rows, 2304 cells
-    static_assert(kTileH % kMomSplit == 0, "parts are whole rows");
-    extern __shared__ unsigned lds_u[];
-    unsigned* off = lds_u;                         // [kPartCells + 1]
-    unsigned* cur = off + kPartCells + 1;          // [kPartCells]
-    unsigned short* idx = reinterpret_cast<unsigned short*>(cur + kPartCells);   // [kSortChunk] record position inside the round
+    constexpr int kCells = kTileW * kTileH;                                 // 1024
+    constexpr int kPer = kCells / kMomThreads;                              // 4 cells per thread
+    constexpr int kRecs = kSortChunk / kMomThreads;                         // 16 records per thread and round
+    __shared__ unsigned off[kCells + 1];
+    __shared__ float sv[kSortChunk], ssx[kSortChunk], ssy[kSortChunk];
     __shared__ unsigned wave_tot[kMomThreads / 64];
 
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int part = slot % kMomSplit, bin = (slot / kMomSplit) * 8 + xcd;
-    if (bin >= b.nbins) return;
+    const int bin = blockIdx.x;
     const unsigned first = bin_start[bin], count = bin_start[bin + 1] - first;
     const int bx = bin % b.bins_x, by = bin / b.bins_x;
-    const int c0 = bx * kTileW, r0 = by * kTileH + part * kPartRows;
-    const int w = min(kTileW, g.W - c0), h = min(kPartRows, g.st_rows - r0);          // h <= 0: nothing to write
-    const unsigned cell0 = (unsigned)(part * kPartCells);
+    const int c0 = bx * kTileW, r0 = by * kTileH;
+    const int w = min(kTileW, g.W - c0), h = min(kTileH, g.st_rows - r0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kPer = (kPartCells + kMomThreads - 1) / kMomThreads;     // 5 cells per thread in the scan (the last own fewer)
 
     for (unsigned cbase = 0; cbase == 0 || cbase < count; cbase += kSortChunk) {
         const unsigned cn = min((unsigned)kSortChunk, count - cbase);
         const uint4* rec = records + first + cbase;
-        for (int i = threadIdx.x; i < kPartCells; i += kMomThreads) cur[i] = 0;
+        uint4 rc[kRecs];
+#pragma unroll
+        for (int k = 0; k < kRecs; ++k) {
+            const unsigned j = threadIdx.x + k * kMomThreads;
+            rc[k] = j < cn ? rec[j] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+        }
+        for (int i = threadIdx.x; i <= kCells; i += kMomThreads) off[i] = 0;
         __syncthreads();
-        // ONE pass over the records' cell indices: the LDS atomic that counts a cell's records also returns the
-        // record's rank inside its cell, and (cell, rank) stays in a register until the scan has turned the counts into
-        // offsets -- the records are not read a second time, and there is no second round of LDS atomics.
-        // Eight independent loads in flight per lane.
-        constexpr int kTrips = kSortChunk / (8 * kMomThreads);       // 8: up to 64 records per thread and round
-        unsigned cr[kTrips * 8];                                     // cell | rank << 16 (both < 2^16)
+        // counting sort by cell: the counting atomic returns the record's rank inside its cell
+        unsigned rk[kRecs];
 #pragma unroll
-        for (int it = 0; it < kTrips; ++it) {
-            const unsigned j0 = threadIdx.x + it * 8 * kMomThreads;
-            unsigned lc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned j = j0 + u * kMomThreads;
-                lc[u] = j < cn ? rec[j].x - cell0 : 0xFFFFFFFFu;     // cells of other parts wrap far above kPartCells
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                cr[it * 8 + u] = 0xFFFFFFFFu;
-                if (lc[u] < (unsigned)kPartCells) cr[it * 8 + u] = lc[u] | (atomicAdd(&cur[lc[u]], 1u) << 16);
-            }
+        for (int k = 0; k < kRecs; ++k) {
+            rk[k] = 0;
+            if (rc[k].x < (unsigned)kCells) rk[k] = atomicAdd(&off[rc[k].x], 1u);
         }
         __syncthreads();
-        // exclusive scan of cur -> off (thread t owns cells [t*kPer, (t+1)*kPer))
-        const int s_lo = min((int)threadIdx.x * kPer, kPartCells), s_hi = min(s_lo + kPer, kPartCells);
-        unsigned s = 0;
-        for (int c = s_lo; c < s_hi; ++c) s += cur[c];
-        unsigned incl = s;
+        {
+            const int lo = threadIdx.x * kPer;
+            unsigned c[kPer], s = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        unsigned run = incl - s;
-        for (int wv = 0; wv < wave; ++wv) run += wave_tot[wv];
-        for (int c = s_lo; c < s_hi; ++c) {
-            unsigned cc = cur[c];
-            off[c] = run;
-            run += cc;
-        }
-        if (threadIdx.x == kMomThreads - 1) off[kPartCells] = run;
-        __syncthreads();
+            for (int q = 0; q < kPer; ++q) { c[q] = off[lo + q]; s += c[q]; }
+            unsigned incl = s;
 #pragma unroll
-        for (int it = 0; it < kTrips; ++it)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned c = cr[it * 8 + u];
-                if (c != 0xFFFFFFFFu) idx[off[c & 0xFFFFu] + (c >> 16)] = (unsigned short)(threadIdx.x + (it * 8 + u) * kMomThreads);
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
             }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            unsigned run = incl - s;
+            for (int wv = 0; wv < wave; ++wv) run += wave_tot[wv];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) { off[lo + q] = run; run += c[q]; }
+            if (threadIdx.x == kMomThreads - 1) off[kCells] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kRecs; ++k) {
+            if (rc[k].x >= (unsigned)kCells) continue;
+            const unsigned pos = off[rc[k].x] + rk[k];
+            sv[pos] = __uint_as_float(rc[k].y);
+            ssx[pos] = __uint_as_float(rc[k].z);
+            ssy[pos] = __uint_as_float(rc[k].w);
+        }
         __syncthreads();
 
-        // per cell: fold its records into P (x2) moments held in registers, write the planes.  The first four
-        // records of the thread's NEXT cell are fetched before the current cell is folded: the gather is a chain of
-        // LDS read -> address -> global load, and with eight waves per CU nothing else hides it.
-        struct CellRecs { unsigned e0, e1; uint4 r[4]; };
-        auto fetch = [&](int cell) {
-            CellRecs c;
-            c.e0 = c.e1 = 0;
-            c.r[0] = c.r[1] = c.r[2] = c.r[3] = make_uint4(0u, 0u, 0u, 0u);
-            if (cell < kPartCells) {
-                c.e0 = off[cell];
-                c.e1 = off[cell + 1];
-                if (c.e1 > c.e0) {
-                    const unsigned last = c.e1 - 1;                // clamped, not predicated: plain global loads
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) c.r[q] = rec[idx[min(c.e0 + q, last)]];
-                }
-            }
-            return c;
-        };
-        CellRecs nxt = fetch(threadIdx.x);
-        for (int cell = threadIdx.x; cell < kPartCells; cell += kMomThreads) {
-            const CellRecs cr4 = nxt;
-            nxt = fetch(cell + kMomThreads);
-            const int ly = cell / kTileW, lx = cell - ly * kTileW;
-            if (lx >= w || ly >= h) continue;
+        // a wave folds one row of the tile at a time: lane = cell, 256-byte plane stores
+        for (int ly = wave; ly < kTileH; ly += kMomThreads / 64) {
+            const int lx = lane;
+            if (ly >= h) break;                                             // wave-uniform
+            const int cell = ly * kTileW + lx;
+            const unsigned e0 = off[cell];
+            const unsigned cnt = min(off[cell + 1] - e0, (unsigned)kSortChunk);   // (the bound only guards the loop)
             float av[P], aw[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) { av[p] = 0.f; aw[p] = 0.f; }
-            const unsigned e0 = cr4.e0, e1 = cr4.e1;
-            // fold one record into the P (x2) accumulators
-            auto fold = [&](const uint4& rc) {
-                const float val = __uint_as_float(rc.y), sx = __uint_as_float(rc.z), sy = __uint_as_float(rc.w);
-                float mx[K + 1], ny[K + 1];
-                // m_k = T_k(2 s') * envelope: T_0 = 1, T_1 = x, T_(k+1) = 2 x T_k - T_(k-1), x = 2 s' in [-1, 1)
-                const float x2 = 2.0f * sx, y2 = 2.0f * sy;
-                mx[0] = expf(-(sx * sx) * inv2sx2);
-                ny[0] = expf(-(sy * sy) * inv2sy2);
-                mx[1] = mx[0] * x2;
-                ny[1] = ny[0] * y2;
+            for (unsigned e = 0; __any(e < cnt); ++e) {
+                if (e < cnt) {
+                    const float val = sv[e0 + e], sx = ssx[e0 + e], sy = ssy[e0 + e];
+                    float mx[K + 1], ny[K + 1];
+                    // m_k = T_k(2 s') * envelope: T_0 = 1, T_1 = x, T_(k+1) = 2 x T_k - T_(k-1), x = 2 s' in [-1, 1)
+                    const float x2 = 2.0f * sx, y2 = 2.0f * sy;
+                    mx[0] = expf(-(sx * sx) * inv2sx2);
+                    ny[0] = expf(-(sy * sy) * inv2sy2);
+                    mx[1] = mx[0] * x2;
+                    ny[1] = ny[0] * y2;
 #pragma unroll
-                for (int k = 2; k <= K; ++k) {
-                    mx[k] = 2.0f * x2 * mx[k - 1] - mx[k - 2];
-                    ny[k] = 2.0f * y2 * ny[k - 1] - ny[k - 2];
-                }
-                int p = 0;
+                    for (int k = 2; k <= K; ++k) {
+                        mx[k] = 2.0f * x2 * mx[k - 1] - mx[k - 2];
+                        ny[k] = 2.0f * y2 * ny[k - 1] - ny[k - 2];
+                    }
+                    int p = 0;
 #pragma unroll
-                for (int k = 0; k <= K; ++k) {
+                    for (int k = 0; k <= K; ++k) {
 #pragma unroll
-                    for (int l = 0; l <= K - k; ++l) {
-                        const float m = mx[k] * ny[l];
-                        if (MASK & 1) av[p] += val * m;
-                        if (MASK & 2) aw[p] += m;
-                        ++p;
+                        for (int l = 0; l <= K - k; ++l) {
+                            const float m = mx[k] * ny[l];
+                            if (MASK & 1) av[p] += val * m;
+                            if (MASK & 2) aw[p] += m;
+                            ++p;
+                        }
                     }
                 }
-            };
-            if (e1 > e0) {
-                const unsigned left0 = e1 - e0;
-                fold(cr4.r[0]);
-                if (left0 > 1) fold(cr4.r[1]);
-                if (left0 > 2) fold(cr4.r[2]);
-                if (left0 > 3) fold(cr4.r[3]);
             }
-            // a cell holds ~3 points on average; the rest of a crowded cell, four independent loads at a time
-            for (unsigned e = e0 + 4; e < e1; e += 4) {
-                const unsigned left = e1 - e;
-                const unsigned last = e1 - 1;
-                const uint4 b0 = rec[idx[e]];
-                const uint4 b1 = rec[idx[min(e + 1, last)]];
-                const uint4 b2 = rec[idx[min(e + 2, last)]];
-                const uint4 b3 = rec[idx[min(e + 3, last)]];
-                fold(b0);
-                if (left > 1) fold(b1);
-                if (left > 2) fold(b2);
-                if (left > 3) fold(b3);
-            }
+            if (lx >= w) continue;
             const int64_t gcell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
             if (cbase == 0) {
                 // written once, read by the column pass much later: streamed past the L2
@@ -445,7 +196,7 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
                         if (MASK & 2) mom_w[p * plane_stride + gcell] = aw[p];
                     }
                 }
-            } else if (e1 > e0) {
+            } else if (cnt > 0) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     if (MASK & 1) mom_v[p * plane_stride + gcell] += av[p];
@@ -936,7 +687,7 @@ void plan_bins(MomPlan& p, const GridDev& g) {
     p.bins.bins_x = (g.W + kTileW - 1) / kTileW;
     p.bins.bins_y = (g.st_rows + kTileH - 1) / kTileH;
     p.bins.nbins = p.bins.bins_x * p.bins.bins_y;
-    p.bins.chunk = (p.bins.nbins <= 2560 ? 8 : 4) * kThreads;       // scatter staging: 16 B x chunk + 12 B per bin of LDS
+    p.bins.chunk = 0;                                    // set where the engine is known (moments_gauss)
     p.bins.row0 = 0;
     p.bins.rows = g.st_rows;
     p.bins.sup_shift = 0;
@@ -1021,7 +772,7 @@ struct MomBand {
 bool plan_bands(const pcr_hip_engine* e, const MomPlan& p, std::vector<MomBand>* bands) {
     const GridDev& g = e->gd;
     const int bins_x = (g.W + kTileW - 1) / kTileW;
-    const int max_tile_rows = e->max_bins / bins_x;
+    const int max_tile_rows = b16::max_bins(e) / bins_x;
     const int rows_total = g.st_rows;
     if ((rows_total + kTileH - 1) / kTileH <= max_tile_rows) {                  // one band: the whole window
         if (bands) bands->push_back({g.own_r0, g.own_r1, 0, rows_total});
@@ -1058,27 +809,13 @@ void fill_taps(std::vector<float>& t, int K, int r, double s2) {
 template <int K, unsigned MASK>
 void launch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                     float* mom_v, float* mom_w, int64_t stride) {
-    auto launch = [&](auto kernel, int split) {
-        const int part_cells = kTileW * (kTileH / split);
-        const size_t lds = ((size_t)part_cells * 2 + 1) * sizeof(unsigned) + (size_t)kSortChunk * sizeof(unsigned short) + 16;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        const int blocks = ((p.bins.nbins + 7) / 8) * 8 * split;     // blockIdx = (bin group * split + part) * 8 + xcd
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kMomThreads), lds, e->stream, gw,
-                           p.bins, p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
-    };
-    // One workgroup per bin.  Sharing a bin between 2 or 4 workgroups of one XCD (rows split, PCR_HIP_TUNE_MOM = 2 / 4)
-    // takes the HBM fetches of this kernel from 5.7 GB to 0.85 GB -- the gathers then hit the XCD's L2 -- and makes
-    // it SLOWER (1.07 -> 1.22 / 1.43 ms at sigma = 16): every part streams the whole bin's cell indices, and the
-    // kernel was waiting on the gather's latency, not on bandwidth (profiles/r02_moments_split.md).
-    if constexpr (K == 3 || K == 5) {
-        switch (e->tune_mom) {
-            case 2: return launch(&k_tile_moments<K, MASK, 2, true>, 2);
-            case 4: return launch(&k_tile_moments<K, MASK, 4, true>, 4);
-            case 9: return launch(&k_tile_moments<K, MASK, 1, false>, 1);
-            default: break;
-        }
-    }
-    launch(&k_tile_moments<K, MASK, 1, true>, 1);
+    // PCR_HIP_TUNE_MOM = 9 (experiments): plain instead of non-temporal plane stores
+    if (e->tune_mom == 9)
+        hipLaunchKernelGGL((k_tile_moments<K, MASK, false>), dim3(p.bins.nbins), dim3(kMomThreads), 0, e->stream, gw, p.bins,
+                           p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
+    else
+        hipLaunchKernelGGL((k_tile_moments<K, MASK, true>), dim3(p.bins.nbins), dim3(kMomThreads), 0, e->stream, gw, p.bins,
+                           p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
 }
 
 template <unsigned MASK>
@@ -1127,26 +864,16 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     }
     const int64_t max_cells = (int64_t)e->gd.W * max_rows;
 
-    size_t off = 0;
-    const size_t o_count = off;  off += align256((size_t)max_bins * 4);
-    const size_t o_start = off;  off += align256((size_t)(max_bins + 1) * 4);
-    const size_t o_cursor = off; off += align256((size_t)max_bins * 4);
-    const size_t o_fbc = off;    off += 256;
-    const size_t o_keys = off;   off += align256((size_t)n * 4);
-    const size_t o_fbl = off;    off += align256((size_t)n * 4);
-    const size_t o_rec = off;    off += align256((size_t)n * 16);
+    // scratch: the front-end's buffers, then the moment and U planes of one window
+    const b16::Layout L = b16::layout(0, max_bins, n, (unsigned)kSortChunk);
+    size_t off = L.end;
     const size_t o_mom = off;    off += align256((size_t)kinds * p.P * max_cells * 4);
     const size_t o_u = off;      off += align256((size_t)(p.K + 1) * max_cells * 4);
     int rc = ensure_scratch(e, off);
     if (rc) return rc;
     char* s = e->d_scratch;
-    unsigned* d_count = reinterpret_cast<unsigned*>(s + o_count);
-    unsigned* d_start = reinterpret_cast<unsigned*>(s + o_start);
-    unsigned* d_cursor = reinterpret_cast<unsigned*>(s + o_cursor);
-    unsigned* d_fbc = reinterpret_cast<unsigned*>(s + o_fbc);
-    unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
-    unsigned* d_fbl = reinterpret_cast<unsigned*>(s + o_fbl);
-    uint4* d_rec = reinterpret_cast<uint4*>(s + o_rec);
+    unsigned* d_fbc = reinterpret_cast<unsigned*>(s + L.o_fbc);
+    unsigned* d_fbl = reinterpret_cast<unsigned*>(s + L.o_fbl);
     float* d_mom = reinterpret_cast<float*>(s + o_mom);
     float* d_u = reinterpret_cast<float*>(s + o_u);
 
@@ -1189,7 +916,6 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     const size_t row_lds = (size_t)4 * rw * rs * sizeof(float);
     const int xunits = (eff_tw + cols - 1) / cols;
     const int npr_need = (spanp + 63) / 64;                             // 64-column loads per row of a strip
-    const int blocks = (int)((n + p.bins.chunk - 1) / p.bins.chunk);
 
     int total_bins = 0;
     for (const MomBand& mb : bands) {
@@ -1201,8 +927,8 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         g.st_rows = mb.win_rows;
         MomPlan pb = p;
         plan_bins(pb, g);
-        pb.bins.chunk = p.bins.chunk;                                   // one launch shape for every band
-        if (pb.bins.nbins > 2560 && pb.bins.chunk != 4 * kThreads) return fail(PCR_HIP_CUDA_ERROR, "moment path: band larger than planned");
+        pb.bins.chunk = b16::chunk_of<MomentMaker>(e);
+        if (pb.bins.nbins > max_bins) return fail(PCR_HIP_CUDA_ERROR, "moment path: band larger than planned");
         const BinGeom& b = pb.bins;
         total_bins += b.nbins;
         const int64_t cells = (int64_t)g.W * g.st_rows;
@@ -1210,32 +936,15 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         float* mom_w = (mask & 2) ? d_mom + ((mask & 1) ? (int64_t)p.P * cells : 0) : nullptr;
         const int64_t win_off = (int64_t)mb.win_r0 * g.W;             // the window's first row in the state planes
 
-        PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
-        PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));
-        {
-            ScopedKernelTimer t(e, "k_mom_count");
-            hipLaunchKernelGGL(k_mom_count, dim3(blocks), dim3(kMomCountThreads), (size_t)b.nbins * 4, e->stream, g, b, x, y, v, n,
-                               d_keys, d_count, d_fbl, d_fbc, e->d_touched, e->d_counters);
-        }
-        {
-            ScopedKernelTimer t(e, "k_mom_scan");
-            hipLaunchKernelGGL(k_mom_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, d_count, d_start, d_cursor);
-        }
-        {
-            ScopedKernelTimer t(e, "k_mom_scatter");
-            const size_t lds = (size_t)b.chunk * 16 + (size_t)b.nbins * 12;
-            auto launch = [&](auto kernel) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds, e->stream, g, b, d_keys, x, y, v, n, d_cursor, d_rec);
-            };
-            if (b.chunk == 8 * kThreads) launch(&k_mom_scatter<8>);
-            else launch(&k_mom_scatter<4>);
-        }
+        PCR_HIP_TRY(hipMemsetAsync(d_fbc, 0, 4, e->stream));           // this band's list (painted at the end of the band)
+        b16::Buffers bb{};
+        rc = b16::bin(e, g, b, MomentMaker{}, x, y, v, n, (unsigned)kSortChunk, L, &bb);
+        if (rc) return rc;
         {
             ScopedKernelTimer t(e, "k_tile_moments");
-            if (mask == 1) dispatch_moments<1>(e, g, pb, d_rec, d_start, mom_v, mom_w, cells);
-            else if (mask == 2) dispatch_moments<2>(e, g, pb, d_rec, d_start, mom_v, mom_w, cells);
-            else dispatch_moments<3>(e, g, pb, d_rec, d_start, mom_v, mom_w, cells);
+            if (mask == 1) dispatch_moments<1>(e, g, pb, bb.records, bb.bin_start, mom_v, mom_w, cells);
+            else if (mask == 2) dispatch_moments<2>(e, g, pb, bb.records, bb.bin_start, mom_v, mom_w, cells);
+            else dispatch_moments<3>(e, g, pb, bb.records, bb.bin_start, mom_v, mom_w, cells);
         }
         // convolutions, per plane kind
         const dim3 col_grid((g.W + 63) / 64, g.tiles_y * yblocks, p.K + 1);

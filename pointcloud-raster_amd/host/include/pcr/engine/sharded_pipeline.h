@@ -1,0 +1,63 @@
+// sharded_pipeline.h -- one grid over the GPUs of a node, from C++: Pipeline on this rank's row block + the native
+// halo exchange (pcr_hip_comm_*: RCCL send/recv to rank +- 1 over xGMI, include/pcr_hip.h).
+//
+// The reference's Pipeline is single-device (include/pcr/engine/pipeline.h:68 `cuda_device_id`); this class is new
+// work at the same API level (create / ingest / finalize / result), so that a C++ caller can shard without Python:
+//
+//     uint8_t id[ShardedPipeline::kIdBytes];
+//     if (rank == 0) ShardedPipeline::make_id(id);
+//     /* carry id to every rank (MPI_Bcast, a file, ...) */
+//     auto sp = ShardedPipeline::create(cfg /* WHOLE grid */, id, rank, world, device);
+//     sp->ingest(cloud);   // any superset of the points whose centre row this rank owns
+//     sp->finalize();      // halo reduce + touched-tile union + local finalize
+//     sp->result();        // rows [row_begin(), row_end()) of every band
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+
+#include "pcr/engine/pipeline.h"
+
+struct pcr_hip_comm;          // include/pcr_hip.h
+
+namespace pcr {
+
+class ShardedPipeline {
+public:
+    static constexpr int kIdBytes = 128;
+    ~ShardedPipeline();
+    ShardedPipeline(const ShardedPipeline&) = delete;
+    ShardedPipeline& operator=(const ShardedPipeline&) = delete;
+
+    /// Rank 0: the communicator's bootstrap id (ncclUniqueId).
+    static Status make_id(uint8_t* id128);
+    /// Rows [r0, r1) of `rank`: contiguous, balanced, edges multiples of `align` (align = tile height: no exchange).
+    static std::pair<int, int> row_block(int rank, int world, int height, int align = 1);
+    /// Collective over the `world` ranks.  nullptr on failure (see create_error()).
+    static std::unique_ptr<ShardedPipeline> create(PipelineConfig cfg, const uint8_t* id128, int rank, int world,
+                                                   int device, int align = 1);
+    static const std::string& create_error();
+
+    Status ingest(const PointCloud& cloud);
+    /// The exchange alone (finalize() calls it): apron rows to their owners, touched-tile union.
+    Status exchange();
+    Status finalize();
+    const Grid* result() const { return pipe_->result(); }
+    Pipeline& pipeline() { return *pipe_; }
+    int row_begin() const { return r0_; }
+    int row_end() const { return r1_; }
+    int halo_rows() const { return halo_; }
+    bool tiles_local() const { return tiles_local_; }      // every block edge on a reference-tile row: nothing to exchange
+    uint64_t bytes_sent() const;
+
+private:
+    ShardedPipeline() = default;
+    std::unique_ptr<Pipeline> pipe_;
+    ::pcr_hip_comm* comm_ = nullptr;
+    int rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, halo_ = 0, width_ = 0;
+    bool tiles_local_ = false;
+};
+
+}  // namespace pcr

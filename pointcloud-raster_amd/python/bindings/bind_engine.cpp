@@ -6,6 +6,7 @@
 #include "pcr/engine/filter.h"
 #include "pcr/engine/glyph.h"
 #include "pcr/engine/pipeline.h"
+#include "pcr/engine/sharded_pipeline.h"
 
 using namespace pcr;
 
@@ -186,4 +187,30 @@ void bind_engine(py::module_& m) {
           "Why the last Pipeline.create() on this thread returned None");
     m.def("device_count", &cuda_device_count);
     m.def("device_name", &cuda_device_name, py::arg("device_id") = 0);
+
+    // ---- the C++ ShardedPipeline (native RCCL exchange, pcr/engine/sharded_pipeline.h)
+    py::class_<ShardedPipeline>(m, "NativeShardedPipeline")
+        .def_static("make_id", []() {
+            uint8_t id[ShardedPipeline::kIdBytes];
+            raise_if_error(ShardedPipeline::make_id(id));
+            return py::bytes(reinterpret_cast<const char*>(id), ShardedPipeline::kIdBytes);
+        })
+        .def_static("row_block", &ShardedPipeline::row_block, py::arg("rank"), py::arg("world"), py::arg("height"),
+                    py::arg("align") = 1)
+        .def_static("create", [](const PipelineConfig& cfg, const py::bytes& id, int rank, int world, int device, int align) {
+            const std::string s = id;
+            if (s.size() != (size_t)ShardedPipeline::kIdBytes) throw std::runtime_error("NativeShardedPipeline: the id must be 128 bytes");
+            return ShardedPipeline::create(cfg, reinterpret_cast<const uint8_t*>(s.data()), rank, world, device, align);
+        }, py::arg("cfg"), py::arg("id"), py::arg("rank"), py::arg("world"), py::arg("device"), py::arg("align") = 1)
+        .def_static("create_error", &ShardedPipeline::create_error)
+        .def("ingest", [](ShardedPipeline& p, const PointCloud& c) { raise_if_error(p.ingest(c)); })
+        .def("exchange", [](ShardedPipeline& p) { raise_if_error(p.exchange()); })
+        .def("finalize", [](ShardedPipeline& p) { raise_if_error(p.finalize()); })
+        .def("result", &ShardedPipeline::result, py::return_value_policy::reference_internal)
+        .def("pipeline", &ShardedPipeline::pipeline, py::return_value_policy::reference_internal)
+        .def("row_begin", &ShardedPipeline::row_begin)
+        .def("row_end", &ShardedPipeline::row_end)
+        .def("halo_rows", &ShardedPipeline::halo_rows)
+        .def("tiles_local", &ShardedPipeline::tiles_local)
+        .def("bytes_sent", &ShardedPipeline::bytes_sent);
 }

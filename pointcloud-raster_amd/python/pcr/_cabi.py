@@ -57,6 +57,10 @@ class ScatterStats(C.Structure):
 
 # every symbol include/pcr_hip.h declares: name -> argtypes (restype is int unless noted)
 _VP, _SZ, _I64, _U64, _U32 = C.c_void_p, C.c_size_t, C.c_int64, C.c_uint64, C.c_uint32
+class HaloPlane(C.Structure):
+    _fields_ = [("d_plane", C.c_void_p), ("kind", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
 SYMBOLS = {
     "pcr_hip_last_error": None,
     "pcr_hip_abi_version": [],
@@ -91,6 +95,15 @@ SYMBOLS = {
     "pcr_hip_route_scatter": [_VP, _U64, C.c_int, _VP, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32), _VP],
     "pcr_hip_absmax_f32": [_VP, _U64, C.POINTER(C.c_float), _VP],
     "pcr_hip_absmax_f32_masked": [_VP, _VP, _U64, _VP, C.POINTER(C.c_float), _VP],
+    "pcr_hip_comm_available": [],
+    "pcr_hip_comm_unique_id": [_VP],
+    "pcr_hip_comm_create": [C.POINTER(_VP), _VP, C.c_int, C.c_int, C.c_int],
+    "pcr_hip_comm_destroy": [_VP],
+    "pcr_hip_comm_rank": [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "pcr_hip_comm_halo_reduce": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP],
+    "pcr_hip_comm_allreduce_max_u32": [_VP, _VP, C.c_int, _VP],
+    "pcr_hip_comm_allreduce_sum_f64": [_VP, _VP, C.c_int, _VP],
+    "pcr_hip_comm_stats": [_VP, C.POINTER(_U64), C.POINTER(_U64)],
     "pcr_hip_state_floats": [C.c_int, C.POINTER(C.c_int)],
     "pcr_hip_plane_fill": [_VP, C.c_float, _I64, _VP],
     "pcr_hip_state_init": [C.c_int, _VP, _I64, _VP],

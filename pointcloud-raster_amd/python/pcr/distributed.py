@@ -227,6 +227,25 @@ def _route_cloud_on_current_stream(cloud, grid_cfg, blocks, rank, world, group, 
     return out
 
 
+def _native_comm(rank, world, device, group=None):
+    """pcr_hip_comm over RCCL: rank 0 makes the 128-byte id, torch.distributed only carries it."""
+    import ctypes as C
+    from . import _cabi as A
+    L = A.lib()
+    if not L.pcr_hip_comm_available():
+        raise RuntimeError("ShardedPipeline(comm='native'): RCCL is not available to libpcr_hip.so")
+    box = [None]
+    if rank == 0:
+        buf = (C.c_uint8 * 128)()
+        A.check(L.pcr_hip_comm_unique_id(buf))
+        box[0] = bytes(buf)
+    dist.broadcast_object_list(box, src=0, group=group)
+    ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    handle = C.c_void_p()
+    A.check(L.pcr_hip_comm_create(C.byref(handle), ident, rank, world, int(device)))
+    return handle
+
+
 class ShardedPipeline:
     """pcr.Pipeline on this rank's row block + the halo exchange.  Usage (one process per GPU):
 
@@ -235,9 +254,17 @@ class ShardedPipeline:
         sp.result()                                    # rows [r0, r1) of every band
     """
 
-    def __init__(self, cfg, rank, world, device_id=None, align=1, group=None):
+    def __init__(self, cfg, rank, world, device_id=None, align=1, group=None, comm="torch"):
+        """comm = "torch": the exchange runs through torch.distributed (nccl = RCCL on device tensors; gloo stages through
+        host memory -- CPU tests and one-GPU rehearsals).  comm = "native": through the library's own pcr_hip_comm_*
+        (include/pcr_hip.h: ncclSend / ncclRecv to rank +- 1 on the engine's stream, merged by a HIP kernel), bootstrapped
+        by a unique id that rank 0 makes and torch.distributed merely carries to the other ranks."""
         import pcr
+        if comm not in ("torch", "native"):
+            raise ValueError("ShardedPipeline: comm must be 'torch' or 'native'")
         self.rank, self.world, self.group = rank, world, group
+        self.comm_kind = comm
+        self._comm = None
         self.grid = cfg.grid
         self.exchange_ms = None              # set by exchange(timed=True)
         self.blocks = [row_block(r, world, cfg.grid.height, align) for r in range(world)]
@@ -257,6 +284,20 @@ class ShardedPipeline:
         # shared between ranks and the flags are purely local: a Point-glyph run then needs no collective at all.
         th = cfg.grid.tile_height
         self.tiles_local = all(b0 % th == 0 or b0 >= cfg.grid.height for b0, _ in self.blocks)
+        if comm == "native" and world > 1:
+            self._comm = _native_comm(rank, world, cfg.cuda_device_id, group)
+
+    def close(self):
+        if self._comm is not None:
+            from . import _cabi as A
+            A.lib().pcr_hip_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _plane_tensors(self):
         if self._views is None:
@@ -327,6 +368,8 @@ class ShardedPipeline:
         if self.world == 1 or self.tiles_local:
             return
         planes = self._plane_tensors()
+        if self._comm is not None:
+            return self._exchange_native(planes, timed)
         # Run the collectives ON the engine's stream (wrapped as a torch ExternalStream): RCCL orders
         # itself after the scatter kernels and before the finalize kernels by stream order alone, no
         # host synchronisation inside the step.  (gloo staging copies synchronise by themselves.)
@@ -352,6 +395,33 @@ class ShardedPipeline:
         if timed:
             e1.synchronize()
             self.exchange_ms = e0.elapsed_time(e1)
+
+    def _exchange_native(self, planes, timed):
+        """pcr_hip_comm_halo_reduce + pcr_hip_comm_allreduce_max_u32 on the engine's stream (no torch in the data path)."""
+        import ctypes as C
+        from . import _cabi as A
+        L = A.lib()
+        stream = self.pipe.stream_ptr()
+        if timed:
+            ev = [C.c_void_p(), C.c_void_p()]
+            for e in ev:
+                A.check(L.pcr_hip_event_create(C.byref(e)))
+            A.check(L.pcr_hip_event_record(ev[0], stream))
+        if self.halo > 0 and planes:
+            arr = (A.HaloPlane * len(planes))()
+            for k, (t, kind) in enumerate(planes):
+                arr[k].d_plane, arr[k].kind = t.data_ptr(), kind
+            A.check(L.pcr_hip_comm_halo_reduce(self._comm, arr, len(planes), self.width, self.pipe.state_row_begin(),
+                                               self.pipe.state_row_count(), self.own[0], self.own[1], self.halo, stream))
+        A.check(L.pcr_hip_comm_allreduce_max_u32(self._comm, self._touched.data_ptr(), self._touched.numel(), stream))
+        if timed:
+            A.check(L.pcr_hip_event_record(ev[1], stream))
+            A.check(L.pcr_hip_stream_synchronize(stream))
+            ms = C.c_float()
+            A.check(L.pcr_hip_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+            self.exchange_ms = float(ms.value)
+            for e in ev:
+                L.pcr_hip_event_destroy(e)
 
     def collectives_per_step(self):
         """What exchange() issues on this rank: (point-to-point halo messages, all-reduces)."""
