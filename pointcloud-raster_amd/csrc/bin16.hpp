@@ -14,7 +14,8 @@
 // matter only: whatever the placement, the same records land in the same tile.
 //
 // A Maker turns a routed point into its record:
-//     static constexpr int kPer;                                        points per thread of the scatter pass (x 1024 = chunk)
+//     static constexpr int kPer, kBatch;                                points per thread of the scatter pass (x threads = chunk);
+//                                                                       how many of them are loaded before the first is routed
 //     struct Chan;                                                      per-point channel values it needs
 //     Chan load(uint64_t i) const;                                      issued with the x, y, v loads of a batch
 //     bool make(g, b, routed, pg, value, chan, uint4& rec) const;       fills rec.y/.z/.w; false: the record cannot hold
@@ -209,7 +210,7 @@ k_b16_scan(int nbins, unsigned item_records, const unsigned* __restrict__ cnt, u
 // THREADS: 1024 (one workgroup per CU), or 512: two workgroups per CU, one's loads and stores behind the other's ranking
 // and reservations, at half the chunk.
 template <class Maker, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, 4)          // <= 128 VGPRs: two 512-thread workgroups per CU
 k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, const double* __restrict__ y,
               const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor, uint4* __restrict__ records,
               unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count) {
@@ -220,7 +221,10 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
     const uint64_t base = (uint64_t)blockIdx.x * (THREADS * kScatPer);
     uint4 rec[kScatPer];                                     // .x = bin << 16 | local cell until the store
     unsigned rank[kScatPer];
-    constexpr int kBatch = 4;
+    // every load of the chunk is issued before the first point is routed: one memory latency per workgroup instead of
+    // one per batch (72 % of this kernel's wave-cycles were waits, profiles/r03_gauss1_sq.md); a routed point's record
+    // takes the registers its x, y, value came in
+    constexpr int kBatch = Maker::kBatch;
 #pragma unroll
     for (int k0 = 0; k0 < kScatPer; k0 += kBatch) {
         double wx[kBatch], wy[kBatch];

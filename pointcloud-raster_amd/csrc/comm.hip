@@ -19,7 +19,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 using namespace pcrhip;
@@ -44,9 +46,37 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // ONE RCCL per process, and the one that belongs to the HIP runtime in use:
+        //  1. a copy the process has already loaded (torch's bundled librccl.so has no SONAME: it is known by that name);
+        //  2. PCR_HIP_RCCL = explicit path;
+        //  3. the sibling of the libamdhip64 this library is running on (torch/lib/librccl.so next to torch's runtime,
+        //     /opt/rocm/lib/librccl.so.1 next to ROCm's) -- a second RCCL with its own rocm_smi / roctx copies next to
+        //     the host's ends in a double free at process exit;
+        //  4. the loader's search path.
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
             if (r.lib) break;
+        }
+        if (!r.lib) {
+            if (const char* forced = std::getenv("PCR_HIP_RCCL")) r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.lib) {
+            Dl_info info;
+            if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+                std::string dir(info.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) {
+                    dir.resize(slash + 1);
+                    for (const char* leaf : {"librccl.so.1", "librccl.so"}) {
+                        r.lib = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_GLOBAL);
+                        if (r.lib) break;
+                    }
+                }
+            }
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) { r.error = std::string("RCCL not found: ") + dlerror(); return; }
         auto sym = [&](const char* n) -> void* {

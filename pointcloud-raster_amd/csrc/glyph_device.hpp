@@ -330,4 +330,29 @@ __device__ __forceinline__ void line_walk_wave(const LineParams& q, bool valid, 
     }
 }
 
+// The same walk when every segment of the wave lies inside its clip rectangle AND inside the LDS window (the usual
+// case: reference tiles are thousands of cells wide, segments tens): no clip test per cell, and the cell's position is
+// carried as the window index li directly (li += +-1 for an x move, +-lw for a y move) instead of (cx, cy).  The tile
+// kernels are bound by vector-instruction issue (a wave64 instruction holds its SIMD for four cycles); this form
+// spends ~14 of them per visited cell where the general one spends ~30.  sink.add_at(li, v): window index, no checks.
+template <typename Sink>
+__device__ __forceinline__ void line_walk_wave_inside(const LineParams& q, bool valid, int li0, int lw, Sink& sink) {
+    int ddx = abs(q.ix1 - q.ix0), ddy = abs(q.iy1 - q.iy0);
+    const int stepx = q.ix0 < q.ix1 ? 1 : -1, stepy = q.iy0 < q.iy1 ? lw : -lw;
+    int err = ddx - ddy, li = li0;
+    if (!valid) { ddx = ddy = -1; }
+    int left = max(ddx, ddy) + 1;
+    int longest = left;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
+    for (int step = 0; step < longest; ++step) {
+        if (left > 0) sink.add_at(li, q.val);
+        --left;
+        const int e2 = 2 * err;
+        const bool mx = e2 > -ddy, my = e2 < ddx;
+        err += (mx ? -ddy : 0) + (my ? ddx : 0);
+        li += (mx ? stepx : 0) + (my ? stepy : 0);
+    }
+}
+
 }  // namespace pcrhip

@@ -91,6 +91,11 @@ struct LineLdsSink {
             if (MASK & PCR_HIP_PLANE_WGT) atomic_add_f32(pl.wgt + cell, 1.0f);
         }
     }
+    // a cell known to lie inside the window, by its window index (line_walk_wave_inside)
+    __device__ __forceinline__ void add_at(int li, float vw) {
+        if (MASK & PCR_HIP_PLANE_SUM) unsafeAtomicAdd(&t_s[li], (double)vw);
+        if (MASK & PCR_HIP_PLANE_WGT) atomicAdd(&t_c[li], 1u);
+    }
 };
 
 // ---- Gaussian tiles ---------------------------------------------------------------------------------
@@ -217,7 +222,7 @@ k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const GlyphRec* _
 // offset (a garbage half_length: |offset| > 32000 cells) goes to the list and is walked by the direct form.
 struct LineRecMaker {
     static constexpr bool kCentre = false;
-    static constexpr int kPer = 12;                           // the f64 sincos of the end points needs the registers
+    static constexpr int kPer = 12, kBatch = 6;               // the f64 sincos of the end points needs the registers
     GlyphDev gl;
     struct Chan { float dir, hl; };
     __device__ __forceinline__ Chan load(uint64_t i) const {
@@ -283,7 +288,12 @@ k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ re
             q.ix1 = ox + (int)(short)(cur.w & 0xFFFFu);
             q.iy1 = oy + (int)(short)(cur.w >> 16);
         }
-        line_walk_wave(q, valid, sink);
+        // the whole wave's segments inside their clip rectangles and the window (bounding boxes): the short walk
+        const int bx0 = min(q.ix0, q.ix1), bx1 = max(q.ix0, q.ix1), by0 = min(q.iy0, q.iy1), by1 = max(q.iy0, q.iy1);
+        const bool inside = !valid || (bx0 >= max(q.cx0, sink.x0) && bx1 < min(q.cx1, sink.x0 + sink.lw) &&
+                                       by0 >= max(q.cy0, sink.y0) && by1 < min(q.cy1, sink.y0 + sink.lh));
+        if (__all(inside)) line_walk_wave_inside(q, valid, (q.iy0 - sink.y0) * sink.lw + (q.ix0 - sink.x0), sink.lw, sink);
+        else line_walk_wave(q, valid, sink);
         cur = nxt;
     }
     __syncthreads();

@@ -47,7 +47,7 @@ namespace {
 // f32 sub-cell offset (glyph_kernels.cu:116-117).
 struct GaussCellMaker {
     static constexpr bool kCentre = true;
-    static constexpr int kPer = 16;
+    static constexpr int kPer = 16, kBatch = 16;
     struct Chan {};
     __device__ __forceinline__ Chan load(uint64_t) const { return Chan{}; }
     __device__ __forceinline__ bool make(const GridDev&, const BinGeom&, const Routed16&, const PointGeom& pg, float val,
@@ -107,6 +107,8 @@ struct CellGauss {
     int cap;                       // records per work item
 };
 
+typedef float pcr_f2 __attribute__((ext_vector_type(2)));
+
 // lane i <- lane i - 1 (lane 0 <- 0): the compiler folds it into v_add_f32_dpp wave_shr:1
 __device__ __forceinline__ float wave_shr1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
@@ -114,9 +116,9 @@ __device__ __forceinline__ float wave_shr1(float v) {
 
 // wx[j] = exp(-((j - R) - u)^2 / 2 s^2), j = 0..2R, as G_d * q^d * E0 (see the file comment)
 template <int R>
-__device__ __forceinline__ void axis_weights(float u, float inv_s2, const float (&G)[4], float (&w)[2 * R + 1]) {
+__device__ __forceinline__ void axis_weights(float u, float inv_s2, const float (&G)[4], float (&w)[2 * R + 1], float scale) {
     const float t = u * inv_s2;
-    const float e0 = __expf(-0.5f * u * t);
+    const float e0 = scale * __expf(-0.5f * u * t);            // scale: 1, or 0 for the null point of an idle lane
     const float q = __expf(t), qi = __expf(-t);
     w[R] = e0;
     float qp = q, qm = qi;
@@ -132,14 +134,15 @@ __device__ __forceinline__ void axis_weights(float u, float inv_s2, const float 
 
 // CUT: which cells of the footprint can fall under the reference's 1e-6 cut-off (decided on the host from the sigmas):
 // 0 none, 1 the four corners only, 2 any.
-// THREADS: 1024 for tall tiles (one workgroup per CU), 512 for tiles half as tall (two per CU: one's record loads,
-// sort and merge behind the other's arithmetic).  SPLIT: column passes of the footprint (2 at R = 3 with both planes).
-template <int R, unsigned MASK, int CUT, int THREADS, int SPLIT>
-__global__ void __launch_bounds__(THREADS)
+// THREADS: R = 3 keeps 98 accumulator registers per lane (two waves per SIMD): two 256-thread workgroups per CU on 20-row
+// tiles (one's record loads, sort and merge behind the other's arithmetic) or one of 512 on 40-row tiles; smaller R:
+// 512 / 1024 threads.
+template <int R, unsigned MASK, int CUT, int THREADS>
+__global__ void __launch_bounds__(THREADS, R == 3 ? 2 : 4)     // R = 3: 49 accumulator pairs per lane, two waves per SIMD
 k_cell_gauss(GridDev g, BinGeom b, CellGauss P, PlanesDev pl, const uint4* __restrict__ records,
              const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
     constexpr int D = 2 * R + 1;
-    constexpr int kTileThreads = THREADS, kRecPerThread = kItemMax / THREADS;
+    constexpr int kTileThreads = THREADS, kRecPerThread = THREADS == 1024 ? 8 : 16;  // an item holds <= that many x THREADS records
     // (declared as double: the dynamic segment follows the static words below and must be 8-byte aligned for ds_add_f64)
     extern __shared__ double lds_raw[];
     if (blockIdx.x >= *n_items) return;
@@ -243,64 +246,56 @@ k_cell_gauss(GridDev g, BinGeom b, CellGauss P, PlanesDev pl, const uint4* __res
         const bool clipped = cnt > 0 && (jlo > 0 || jhi < D - 1 || ilo > 0 || ihi < D - 1);
         const bool any_clipped = __any(clipped);
 
-        // The footprint's columns are accumulated in SPLIT passes over the cell's points, highest columns first: a pass
-        // keeps (2R+1) x (its columns) sums per plane in registers, then feeds them into the per-row shift chains
-        // (after the last pass lane l holds window column l of footprint row i).  Two passes at R = 3 with both planes:
-        // 56 + 42 accumulators instead of 98 at once -- the kernel then fits the 128 registers of a 16-wave CU.
-        float ts[D], tw[D];
-        auto pass = [&](auto j0c, auto j1c) {
-            constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value, NJ = J1 - J0;
-            float as[D][NJ], aw[D][NJ];
+        // acc[i][j] = {sum of v w, sum of w} of footprint cell (i, j), both planes in one register pair: one packed fused
+        // multiply-add per cell and point.  The kernel is bound by vector-instruction ISSUE -- a wave64 instruction holds
+        // its SIMD for four cycles, packed or not (rocprofv3: 6.9e8 instructions, SIMDs 95 % busy at 1.38 ms,
+        // profiles/r03_gauss1_sq.md) -- so the two planes ride on v_pk_fma_f32 (250 -> ~125 instructions per point).
+        pcr_f2 acc[D][D];
 #pragma unroll
-            for (int i = 0; i < D; ++i)
+        for (int i = 0; i < D; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) { as[i][j] = 0.f; aw[i][j] = 0.f; }
-            for (unsigned k = 0; __any(k < cnt); ++k) {
-                if (k < cnt) {
-                    const float val = sv[e0 + k];
-                    float ex[D], ey[D];
-                    axis_weights<R>(ssx[e0 + k], P.inv_s2x, P.gx, ex);
-                    axis_weights<R>(ssy[e0 + k], P.inv_s2y, P.gy, ey);
+            for (int j = 0; j < D; ++j) acc[i][j] = pcr_f2{0.f, 0.f};
+        // Every lane runs every round: a lane whose cell has fewer points folds a NULL point (value 0, x weights 0), so the
+        // body is straight-line code (predicated, every accumulator went through a select per round).
+        for (unsigned k = 0; __any(k < cnt); ++k) {
+            const bool live = k < cnt;
+            const unsigned idx = live ? e0 + k : 0u;
+            const float val = live ? sv[idx] : 0.f;
+            float ex[D], ey[D];
+            axis_weights<R>(ssx[idx], P.inv_s2x, P.gx, ex, live ? 1.f : 0.f);
+            axis_weights<R>(ssy[idx], P.inv_s2y, P.gy, ey, 1.f);
+            pcr_f2 vx[D];                                        // {v wx[j], wx[j]}
 #pragma unroll
-                    for (int i = 0; i < D; ++i) {
-#pragma unroll
-                        for (int j = J0; j < J1; ++j) {
-                            const bool corner = (i == 0 || i == D - 1) && (j == 0 || j == D - 1);
-                            float w = ex[j] * ey[i];
-                            if (CUT == 2 || (CUT == 1 && corner)) w = (w < 1e-6f) ? 0.f : w;      // glyph_kernels.cu:166
-                            if (MASK & 2) aw[i][j - J0] += w;
-                            if (MASK & 1) as[i][j - J0] = fmaf(val, w, as[i][j - J0]);
-                        }
-                    }
-                }
-            }
-            if (any_clipped) {
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = J0; j < J1; ++j)
-                        if (j < jlo || j > jhi || i < ilo || i > ihi) { as[i][j - J0] = 0.f; aw[i][j - J0] = 0.f; }
-            }
+            for (int j = 0; j < D; ++j) vx[j] = pcr_f2{val, 1.0f} * pcr_f2{ex[j], ex[j]};
 #pragma unroll
             for (int i = 0; i < D; ++i) {
 #pragma unroll
-                for (int j = J1 - 1; j >= J0; --j) {
-                    if (j == D - 1) {
-                        ts[i] = as[i][j - J0];
-                        tw[i] = aw[i][j - J0];
-                    } else {
-                        if (MASK & 1) ts[i] = wave_shr1(ts[i]) + as[i][j - J0];
-                        if (MASK & 2) tw[i] = wave_shr1(tw[i]) + aw[i][j - J0];
-                    }
+                for (int j = 0; j < D; ++j) {
+                    const bool corner = (i == 0 || i == D - 1) && (j == 0 || j == D - 1);
+                    float wy = ey[i];
+                    if (CUT == 2 || (CUT == 1 && corner)) wy = (ex[j] * ey[i] < 1e-6f) ? 0.f : wy;       // glyph_kernels.cu:166
+                    acc[i][j] = __builtin_elementwise_fma(vx[j], pcr_f2{wy, wy}, acc[i][j]);
                 }
             }
-        };
-        using std::integral_constant;
-        if constexpr (SPLIT == 2) {
-            pass(integral_constant<int, R + 1>{}, integral_constant<int, D>{});
-            pass(integral_constant<int, 0>{}, integral_constant<int, R + 1>{});
-        } else {
-            pass(integral_constant<int, 0>{}, integral_constant<int, D>{});
+        }
+        if (any_clipped) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (j < jlo || j > jhi || i < ilo || i > ihi) acc[i][j] = pcr_f2{0.f, 0.f};
+        }
+        // columns of neighbouring lanes' footprints meet: after 2R shifts lane l holds window column l of footprint row i
+        float ts[D], tw[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            ts[i] = acc[i][D - 1].x;
+            tw[i] = acc[i][D - 1].y;
+#pragma unroll
+            for (int j = D - 2; j >= 0; --j) {
+                if (MASK & 1) ts[i] = wave_shr1(ts[i]) + acc[i][j].x;
+                if (MASK & 2) tw[i] = wave_shr1(tw[i]) + acc[i][j].y;
+            }
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -379,8 +374,14 @@ bool plan_cells(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, Cell
     const size_t budget = best_h <= 24 ? (size_t)80 * 1024 - 1024 : (size_t)160 * 1024 - 2048;
     const size_t fixed = (size_t)64 * (best_h + 2 * r) * 8 * planes + (((size_t)p.tile_w * best_h + 1 + 3) & ~size_t(3)) * 4;
     if (fixed + 12 * 1024 > budget) return false;
-    const int best_cap = std::min((int)((budget - fixed) / 12) & ~255, kItemMax);
-    p.threads = best_h <= 24 ? 512 : 1024;
+    // Workgroup shape.  R = 3 keeps 98 accumulator registers per lane (~215 VGPRs: two waves per SIMD), i.e. eight
+    // waves per CU: two 256-thread workgroups on 20-row tiles, or one 512-thread workgroup on 40-row tiles.  (Two
+    // column passes over the cell's points -- 56 + 42 accumulators, <= 128 VGPRs, sixteen waves per CU -- cost 1.9x the
+    // arithmetic of a kernel that is issue-bound: 1.89 vs 1.46 ms.  Removed.)
+    const bool heavy = r == 3;
+    if (best_h <= 24) p.threads = heavy ? 256 : 512;
+    else p.threads = heavy ? 512 : 1024;
+    const int best_cap = std::min((int)((budget - fixed) / 12) & ~255, (p.threads == 1024 ? 8 : 16) * p.threads);
     if (p.tile_w * best_h > 8 * p.threads) return false;           // the tile kernel's in-LDS scan: <= 8 cells per thread
     p.tile_h = best_h;
     p.P.cap = best_cap;
@@ -406,19 +407,23 @@ BinGeom cell_bins(const GridDev& g, const CellPlan& p, int row0, int rows) {
 template <int R, unsigned MASK>
 void launch_cells(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const CellPlan& p, const PlanesDev& pl,
                   const uint4* rec, const BinItem* items, const unsigned* n_items, int max_items) {
-    constexpr int S = (R == 3 && MASK == 3) ? 2 : 1;
     auto go = [&](auto kernel, int threads) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         hipLaunchKernelGGL(kernel, dim3(max_items), dim3(threads), p.lds, e->stream, gd, b, p.P, pl, rec, items, n_items);
     };
-    if (p.threads == 512) {
-        if (p.cut == 0) go(&k_cell_gauss<R, MASK, 0, 512, S>, 512);
-        else if (p.cut == 1) go(&k_cell_gauss<R, MASK, 1, 512, S>, 512);
-        else go(&k_cell_gauss<R, MASK, 2, 512, S>, 512);
+    auto by_cut = [&](auto threads_c) {
+        constexpr int T = decltype(threads_c)::value;
+        if (p.cut == 0) go(&k_cell_gauss<R, MASK, 0, T>, T);
+        else if (p.cut == 1) go(&k_cell_gauss<R, MASK, 1, T>, T);
+        else go(&k_cell_gauss<R, MASK, 2, T>, T);
+    };
+    using std::integral_constant;
+    if constexpr (R == 3) {
+        if (p.threads == 256) by_cut(integral_constant<int, 256>{});
+        else by_cut(integral_constant<int, 512>{});
     } else {
-        if (p.cut == 0) go(&k_cell_gauss<R, MASK, 0, 1024, S>, 1024);
-        else if (p.cut == 1) go(&k_cell_gauss<R, MASK, 1, 1024, S>, 1024);
-        else go(&k_cell_gauss<R, MASK, 2, 1024, S>, 1024);
+        if (p.threads == 512) by_cut(integral_constant<int, 512>{});
+        else by_cut(integral_constant<int, 1024>{});
     }
 }
 

@@ -37,7 +37,7 @@ namespace {
 constexpr int kMomThreads = 256;      // per-tile moment reduction: four waves, three workgroups per CU
 constexpr int kPad = 20;              // zero padding of the tap tables (16-output windows, 4 source rows per step)
 constexpr int kTileW = 64, kTileH = 16;                  // a wave folds one row of the tile at a time; ~3 K records staged in LDS
-constexpr int kSortChunk = 4096;                         // records staged per round (48 KB of LDS)
+constexpr int kSortChunk = 3840;                         // records staged per round (45 KB of LDS: three workgroups per CU)
 constexpr int kMaxK = 9;
 constexpr double kTruncationBound = 5e-5;      // make_plan: rigorous bound on the relative error of any weight
 
@@ -53,9 +53,11 @@ __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) &
 // ---- binning: the shared front-end (bin16.hpp) on records {local cell, value, s'x, s'y} -----------------------
 // s' = the reference's f32 sub-cell offset, recentred to [-1/2, 1/2).  A point whose value is not finite, or whose
 // centre cell is not the routed cell (grid edge), cannot be represented by moments: it goes to the list.
+typedef float pcr_f2 __attribute__((ext_vector_type(2)));
+
 struct MomentMaker {
     static constexpr bool kCentre = true;
-    static constexpr int kPer = 16;
+    static constexpr int kPer = 16, kBatch = 16;
     struct Chan {};
     __device__ __forceinline__ Chan load(uint64_t) const { return Chan{}; }
     __device__ __forceinline__ bool make(const GridDev&, const BinGeom&, const b16::Routed16&, const PointGeom& pg, float val,
@@ -83,7 +85,7 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
     constexpr int P = (K + 1) * (K + 2) / 2;
     constexpr int kCells = kTileW * kTileH;                                 // 1024
     constexpr int kPer = kCells / kMomThreads;                              // 4 cells per thread
-    constexpr int kRecs = kSortChunk / kMomThreads;                         // 16 records per thread and round
+    constexpr int kRecs = (kSortChunk + kMomThreads - 1) / kMomThreads;     // 15 records per thread and round
     __shared__ unsigned off[kCells + 1];
     __shared__ float sv[kSortChunk], ssx[kSortChunk], ssy[kSortChunk];
     __shared__ unsigned wave_tot[kMomThreads / 64];
@@ -144,41 +146,47 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
         }
         __syncthreads();
 
-        // a wave folds one row of the tile at a time: lane = cell, 256-byte plane stores
+        // a wave folds one row of the tile at a time: lane = cell, 256-byte plane stores.  (Ordering the cells by record
+        // count so that a wave's 64 cells run the same number of rounds was tried: the fold got ~2x shorter and the plane
+        // stores, no longer row segments, cost 3x that: k_tile_moments 0.54 -> 1.20 ms at K = 3, profiles/r03_moments.md.)
         for (int ly = wave; ly < kTileH; ly += kMomThreads / 64) {
             const int lx = lane;
             if (ly >= h) break;                                             // wave-uniform
             const int cell = ly * kTileW + lx;
             const unsigned e0 = off[cell];
             const unsigned cnt = min(off[cell + 1] - e0, (unsigned)kSortChunk);   // (the bound only guards the loop)
-            float av[P], aw[P];
+            pcr_f2 acc[P];                                                  // {sum of v m, sum of m}
 #pragma unroll
-            for (int p = 0; p < P; ++p) { av[p] = 0.f; aw[p] = 0.f; }
+            for (int p = 0; p < P; ++p) acc[p] = pcr_f2{0.f, 0.f};
+            // every lane runs every round; a lane past its cell's last record folds a null record (weights 0): straight-line
+            // code, no select per accumulator
             for (unsigned e = 0; __any(e < cnt); ++e) {
-                if (e < cnt) {
-                    const float val = sv[e0 + e], sx = ssx[e0 + e], sy = ssy[e0 + e];
-                    float mx[K + 1], ny[K + 1];
-                    // m_k = T_k(2 s') * envelope: T_0 = 1, T_1 = x, T_(k+1) = 2 x T_k - T_(k-1), x = 2 s' in [-1, 1)
-                    const float x2 = 2.0f * sx, y2 = 2.0f * sy;
-                    mx[0] = expf(-(sx * sx) * inv2sx2);
-                    ny[0] = expf(-(sy * sy) * inv2sy2);
-                    mx[1] = mx[0] * x2;
-                    ny[1] = ny[0] * y2;
+                const bool live = e < cnt;
+                const unsigned idx = live ? e0 + e : 0u;
+                const float val = live ? sv[idx] : 0.f, sx = ssx[idx], sy = ssy[idx];
+                float mx[K + 1], ny[K + 1];
+                // m_k = T_k(2 s') * envelope: T_0 = 1, T_1 = x, T_(k+1) = 2 x T_k - T_(k-1), x = 2 s' in [-1, 1)
+                const float x2 = 2.0f * sx, y2 = 2.0f * sy;
+                mx[0] = live ? expf(-(sx * sx) * inv2sx2) : 0.f;
+                ny[0] = expf(-(sy * sy) * inv2sy2);
+                mx[1] = mx[0] * x2;
+                ny[1] = ny[0] * y2;
 #pragma unroll
-                    for (int k = 2; k <= K; ++k) {
-                        mx[k] = 2.0f * x2 * mx[k - 1] - mx[k - 2];
-                        ny[k] = 2.0f * y2 * ny[k - 1] - ny[k - 2];
-                    }
-                    int p = 0;
+                for (int k = 2; k <= K; ++k) {
+                    mx[k] = 2.0f * x2 * mx[k - 1] - mx[k - 2];
+                    ny[k] = 2.0f * y2 * ny[k - 1] - ny[k - 2];
+                }
+                // {av, aw}[p] += {val, 1} * m_kl as ONE packed fused multiply-add: the fold is bound by vector-instruction
+                // issue (a wave64 instruction holds its SIMD for four cycles, packed or not: profiles/r03_gauss1_sq.md)
+                const pcr_f2 v1{val, 1.0f};
+                int p = 0;
 #pragma unroll
-                    for (int k = 0; k <= K; ++k) {
+                for (int k = 0; k <= K; ++k) {
 #pragma unroll
-                        for (int l = 0; l <= K - k; ++l) {
-                            const float m = mx[k] * ny[l];
-                            if (MASK & 1) av[p] += val * m;
-                            if (MASK & 2) aw[p] += m;
-                            ++p;
-                        }
+                    for (int l = 0; l <= K - k; ++l) {
+                        const float m = mx[k] * ny[l];
+                        acc[p] = __builtin_elementwise_fma(v1, pcr_f2{m, m}, acc[p]);
+                        ++p;
                     }
                 }
             }
@@ -189,18 +197,18 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     if (NT) {
-                        if (MASK & 1) __builtin_nontemporal_store(av[p], mom_v + p * plane_stride + gcell);
-                        if (MASK & 2) __builtin_nontemporal_store(aw[p], mom_w + p * plane_stride + gcell);
+                        if (MASK & 1) __builtin_nontemporal_store(acc[p].x, mom_v + p * plane_stride + gcell);
+                        if (MASK & 2) __builtin_nontemporal_store(acc[p].y, mom_w + p * plane_stride + gcell);
                     } else {
-                        if (MASK & 1) mom_v[p * plane_stride + gcell] = av[p];
-                        if (MASK & 2) mom_w[p * plane_stride + gcell] = aw[p];
+                        if (MASK & 1) mom_v[p * plane_stride + gcell] = acc[p].x;
+                        if (MASK & 2) mom_w[p * plane_stride + gcell] = acc[p].y;
                     }
                 }
             } else if (cnt > 0) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    if (MASK & 1) mom_v[p * plane_stride + gcell] += av[p];
-                    if (MASK & 2) mom_w[p * plane_stride + gcell] += aw[p];
+                    if (MASK & 1) mom_v[p * plane_stride + gcell] += acc[p].x;
+                    if (MASK & 2) mom_w[p * plane_stride + gcell] += acc[p].y;
                 }
             }
         }
@@ -222,7 +230,6 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 // (B[i] = output i - 1; its two end entries are never read), and the two files are added at the end.
 // Every step fetches its 20 taps with two scalar loads (the tables sit in the scalar cache); other waves of
 // the SIMD cover that latency.  GM = output groups (4 outputs each) that can meet a non-zero tap.
-typedef float pcr_f2 __attribute__((ext_vector_type(2)));
 typedef pcr_f2 pcr_f2_u __attribute__((aligned(4)));          // a tap pair at any float offset
 
 struct ConvAcc {

@@ -62,7 +62,7 @@ _share_hip_runtime_with_torch()
 
 from ._pcr import (  # noqa: E402,F401
     BBox, BandDesc, CRS, ChannelDesc, CompareOp, DataType, ExecutionMode, FilterPredicate, FilterSpec,
-    GeoTiffOptions, GlyphSpec, GlyphType, Grid, GridConfig, MemoryLocation, NoDataPolicy, Pipeline,
+    GeoTiffOptions, GlyphSpec, GlyphType, Grid, GridConfig, MemoryLocation, NativeShardedPipeline, NoDataPolicy, Pipeline,
     PipelineConfig, PointCloud, PointCloudFormat, PointCloudInfo, PointCloudReader, ProgressInfo,
     ReductionSpec, ReductionType, Status, StatusCode, TileIndex,
     device_count, device_name, pipeline_create_error,
@@ -132,7 +132,7 @@ __all__ = [
     "PointCloudFormat", "GlyphType",
     "BBox", "CRS", "NoDataPolicy", "TileIndex", "Status", "ChannelDesc", "BandDesc",
     "GridConfig", "Grid", "PointCloud", "FilterPredicate", "FilterSpec",
-    "GlyphSpec", "ReductionSpec", "PipelineConfig", "ProgressInfo", "Pipeline",
+    "GlyphSpec", "ReductionSpec", "PipelineConfig", "ProgressInfo", "Pipeline", "NativeShardedPipeline",
     "gaussian_splat_spec", "line_splat_spec",
     "GeoTiffOptions", "write_geotiff", "read_geotiff_info",
     "PointCloudInfo", "read_point_cloud", "write_point_cloud", "read_point_cloud_info", "PointCloudReader",

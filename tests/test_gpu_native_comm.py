@@ -10,85 +10,118 @@ import os
 import socket
 import sys
 
-import numpy as np
 import pytest
-
-import pcr_oracle_py as O
-from conftest import load_cabi
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-@pytest.fixture(scope="module")
-def A():
-    return load_cabi()
+# RCCL is only ever loaded in CHILD processes here: the pytest process itself maps ROCm's HIP runtime (tests that bind the
+# C-ABI directly) and later torch's libraries (tests that import torch); a third party's RCCL in between would be a second
+# copy of rocm_smi / roctx in one process.  A child that crashes at exit fails its test through the exit code.
+_WORLD_ONE = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from conftest import load_cabi
+A = load_cabi()
+L = A.lib()
+assert L.pcr_hip_comm_available() == 1
+ident = (C.c_uint8 * 128)()
+A.check(L.pcr_hip_comm_unique_id(ident))
+assert any(ident)
+comm = C.c_void_p()
+A.check(L.pcr_hip_comm_create(C.byref(comm), ident, 0, 1, 0))
+rank, world = C.c_int(-1), C.c_int(-1)
+A.check(L.pcr_hip_comm_rank(comm, C.byref(rank), C.byref(world)))
+assert (rank.value, world.value) == (0, 1)
+# world 1: both steps are no-ops, but the arguments are still validated
+buf = A.DeviceBuffer.from_numpy(np.ones((8, 16), dtype=np.float32))
+planes = (A.HaloPlane * 1)()
+planes[0].d_plane, planes[0].kind = buf.ptr.value, A.PLANE_SUM
+A.check(L.pcr_hip_comm_halo_reduce(comm, planes, 1, 16, 0, 8, 2, 6, 2, None))
+for bad in ((6, 12),):                                   # owned rows outside the window
+    try:
+        A.check(L.pcr_hip_comm_halo_reduce(comm, planes, 1, 16, 0, 8, bad[0], bad[1], 2, None))
+        raise SystemExit("halo_reduce accepted owned rows outside the state window")
+    except A.PcrHipError:
+        pass
+try:
+    A.check(L.pcr_hip_comm_create(C.byref(C.c_void_p()), ident, 3, 2, 0))     # rank outside [0, world)
+    raise SystemExit("comm_create accepted rank 3 of 2")
+except A.PcrHipError:
+    pass
+words = A.DeviceBuffer.from_numpy(np.arange(4, dtype=np.uint32))
+A.check(L.pcr_hip_comm_allreduce_max_u32(comm, words.ptr, 4, None))          # world 1: identity
+assert (words.to_numpy(np.uint32, 4) == np.arange(4, dtype=np.uint32)).all()
+A.check(L.pcr_hip_comm_destroy(comm))
+print("world-one comm ok")
+"""
 
 
-def test_rccl_loads_and_world_one_communicator(A):
-    L = A.lib()
-    assert L.pcr_hip_comm_available() == 1
-    ident = (C.c_uint8 * 128)()
-    A.check(L.pcr_hip_comm_unique_id(ident))
-    assert any(ident)
-    comm = C.c_void_p()
-    A.check(L.pcr_hip_comm_create(C.byref(comm), ident, 0, 1, 0))
-    rank, world = C.c_int(-1), C.c_int(-1)
-    A.check(L.pcr_hip_comm_rank(comm, C.byref(rank), C.byref(world)))
-    assert (rank.value, world.value) == (0, 1)
-    # world 1: both steps are no-ops, but the arguments are still validated
-    buf = A.DeviceBuffer.from_numpy(np.ones((8, 16), dtype=np.float32))
-    planes = (A.HaloPlane * 1)()
-    planes[0].d_plane, planes[0].kind = buf.ptr.value, A.PLANE_SUM
-    A.check(L.pcr_hip_comm_halo_reduce(comm, planes, 1, 16, 0, 8, 2, 6, 2, None))
-    with pytest.raises(A.PcrHipError):
-        A.check(L.pcr_hip_comm_halo_reduce(comm, planes, 1, 16, 0, 8, 6, 12, 2, None))      # owned rows outside the window
-    with pytest.raises(A.PcrHipError):
-        A.check(L.pcr_hip_comm_create(C.byref(C.c_void_p()), ident, 3, 2, 0))               # rank outside [0, world)
-    words = A.DeviceBuffer.from_numpy(np.arange(4, dtype=np.uint32))
-    A.check(L.pcr_hip_comm_allreduce_max_u32(comm, words.ptr, 4, None))  # world 1: identity
-    np.testing.assert_array_equal(words.to_numpy(np.uint32, 4), np.arange(4, dtype=np.uint32))
-    A.check(L.pcr_hip_comm_destroy(comm))
+def _run_child(code, *args, timeout=240):
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", code, HERE, *args], capture_output=True, text=True, timeout=timeout,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    return out.stdout
+
+
+def test_rccl_loads_and_world_one_communicator():
+    assert "world-one comm ok" in _run_child(_WORLD_ONE)
+
+
+_SHARDED_WORLD_ONE = r"""
+import os, sys
+import numpy as np
+HERE = sys.argv[1]
+ROOT = os.path.dirname(HERE)
+for p in (HERE, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "pointcloud-raster_amd", "python")):
+    sys.path.insert(0, p)
+import pcr
+import pcr_oracle_py as O
+G, n = 200, 40000
+rng = np.random.default_rng(5)
+x, y = rng.uniform(1, G - 1, n), rng.uniform(1, G - 1, n)
+v = rng.uniform(0, 1, n).astype(np.float32)
+cfg = pcr.PipelineConfig()
+cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(G))
+cfg.grid.tile_width, cfg.grid.tile_height = 64, 64
+cfg.grid.compute_dimensions()
+cfg.exec_mode = pcr.ExecutionMode.GPU
+cnt = pcr.ReductionSpec()
+cnt.value_channel, cnt.type = "value", pcr.ReductionType.Count
+cfg.reductions = [pcr.gaussian_splat_spec("value", default_sigma=1.0, max_radius_cells=4.0), cnt]
+ident = pcr.NativeShardedPipeline.make_id()
+assert len(ident) == 128
+sp = pcr.NativeShardedPipeline.create(cfg, ident, 0, 1, 0)
+assert sp is not None, pcr.NativeShardedPipeline.create_error()
+assert (sp.row_begin(), sp.row_end()) == (0, G) and pcr.NativeShardedPipeline.row_block(1, 4, 1000) == (250, 500)
+cloud = pcr.PointCloud.create(n)
+cloud.set_x_array(x)
+cloud.set_y_array(y)
+cloud.add_channel("value", pcr.DataType.Float32)
+cloud.set_channel_array_f32("value", v)
+sp.ingest(cloud.to_device())
+sp.finalize()
+res = sp.result()
+og = O.make_grid((0.0, 0.0, float(G), float(G)), tile=(64, 64))
+assert np.array_equal(np.array(res.band_array(1)), O.run(og, O.COUNT, x, y, v), equal_nan=True)
+gl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=1.0, sigma_y=1.0, max_radius=4.0)
+exact = O.run(og, O.WEIGHTED_AVERAGE, x, y, v, glyph=gl, wide=True).astype(np.float64)
+got = np.array(res.band_array(0)).astype(np.float64)
+m = ~np.isnan(got) & ~np.isnan(exact)
+assert (np.isnan(got) != np.isnan(exact)).sum() <= 4
+assert (np.abs(got[m] - exact[m]) <= 1e-4 * np.maximum(1e-3, np.abs(exact[m]))).all()
+del sp
+print("sharded world-one ok")
+"""
 
 
 def test_native_sharded_pipeline_world_one_matches_oracle():
-    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
-    import pcr
-    G, n = 200, 40000
-    rng = np.random.default_rng(5)
-    x, y = rng.uniform(1, G - 1, n), rng.uniform(1, G - 1, n)
-    v = rng.uniform(0, 1, n).astype(np.float32)
-    cfg = pcr.PipelineConfig()
-    cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(G))
-    cfg.grid.tile_width, cfg.grid.tile_height = 64, 64
-    cfg.grid.compute_dimensions()
-    cfg.exec_mode = pcr.ExecutionMode.GPU
-    cnt = pcr.ReductionSpec()
-    cnt.value_channel, cnt.type = "value", pcr.ReductionType.Count
-    cfg.reductions = [pcr.gaussian_splat_spec("value", default_sigma=1.0, max_radius_cells=4.0), cnt]
-    ident = pcr.NativeShardedPipeline.make_id()
-    assert len(ident) == 128
-    sp = pcr.NativeShardedPipeline.create(cfg, ident, 0, 1, 0)
-    assert sp is not None, pcr.NativeShardedPipeline.create_error()
-    assert (sp.row_begin(), sp.row_end()) == (0, G) and pcr.NativeShardedPipeline.row_block(1, 4, 1000) == (250, 500)
-    cloud = pcr.PointCloud.create(n)
-    cloud.set_x_array(x)
-    cloud.set_y_array(y)
-    cloud.add_channel("value", pcr.DataType.Float32)
-    cloud.set_channel_array_f32("value", v)
-    sp.ingest(cloud.to_device())
-    sp.finalize()
-    res = sp.result()
-    og = O.make_grid((0.0, 0.0, float(G), float(G)), tile=(64, 64))
-    want_c = O.run(og, O.COUNT, x, y, v)
-    np.testing.assert_array_equal(np.array(res.band_array(1)), want_c)
-    gl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=1.0, sigma_y=1.0, max_radius=4.0)
-    exact = O.run(og, O.WEIGHTED_AVERAGE, x, y, v, glyph=gl, wide=True).astype(np.float64)
-    got = np.array(res.band_array(0)).astype(np.float64)
-    m = ~np.isnan(got) & ~np.isnan(exact)
-    assert (np.isnan(got) != np.isnan(exact)).sum() <= 4
-    assert (np.abs(got[m] - exact[m]) <= 1e-4 * np.maximum(1e-3, np.abs(exact[m]))).all()
+    """The C++ ShardedPipeline (pcr.NativeShardedPipeline) at world 1: id from RCCL, no exchange, the unsharded result."""
+    assert "sharded world-one ok" in _run_child(_SHARDED_WORLD_ONE)
 
 
 def _two_rank_worker(rank, port, out_dir):
@@ -136,6 +169,7 @@ def test_two_ranks_on_one_device_native_is_created_or_cleanly_refused(tmp_path):
         if p.is_alive():
             p.kill()
             pytest.fail("native communicator bootstrap hung with two ranks on one device")
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]      # a crash at exit counts
     texts = [open(os.path.join(str(tmp_path), f"native_r{r}.txt")).read() for r in range(2)]
     assert all(t == "ok" or t.startswith("refused: ") for t in texts), texts
     print("two ranks on one device, native comm:", texts)
