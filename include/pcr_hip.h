@@ -181,13 +181,9 @@ typedef struct pcr_hip_engine pcr_hip_engine;
  * Test-only environment knobs, read here: PCR_HIP_DEBUG_MAX_BINS=<n> lowers the number of LDS tiles one binning pass
  * may count (8064) so that the large-grid paths (two-level sort, row bands) are reached on small grids;
  * PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep where the two-level sort would apply.
- * Opt-in: PCR_HIP_ONE_PASS=1 selects the one-pass (sampled provisioning) sort for Point-glyph scatters of >= 2^18 points
- * on one window of <= 4096 LDS tiles: 23 % less HBM traffic, same time (csrc/scatter_binned.hip, k_bin_scatter1);
- * PCR_HIP_DEBUG_PROVISION=<0..100> starves its bin provisions so that tests reach its overflow path.
- * Measurement knobs (A/B runs of tools/ab_env.sh; results do not change): PCR_HIP_TUNE_SCATTER=3 (round 1's k_bin_scatter
- * shape), PCR_HIP_TUNE_REC=1 (k_rec_scatter in 1024-thread groups), PCR_HIP_TUNE_CONV=1|2 (moment path column pass on the
- * vector ALU | on the matrix cores whatever the radius), PCR_HIP_TUNE_MOM=2|4|9 (a moment bin shared by 2 | 4 workgroups;
- * plain instead of non-temporal plane stores), PCR_HIP_TUNE_B=1 (k_bin_scatter phase cycles on stderr; synchronizes). */
+ * (the passes on 16-byte glyph records count up to 16384 tiles: the knob applies to them as it stands);
+ * PCR_HIP_DEBUG_TWO_LEVEL=0 above.  PCR_HIP_TUNE_CONV=1|2 forces the vector-ALU | matrix-core column pass of the moment path
+ * whatever the radius (tests reach both kernels on small shapes; results do not change). */
 int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s);
 int pcr_hip_engine_destroy(pcr_hip_engine* e);
 /* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot

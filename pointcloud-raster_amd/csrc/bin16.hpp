@@ -30,6 +30,7 @@ namespace pcrhip {
 namespace b16 {
 
 constexpr int kCountThreads = 512;
+constexpr int kScatThreads = 512;                         // scatter pass: two workgroups per CU (see chunk_of below)
 constexpr int kVx = 8;                                     // virtual XCDs
 constexpr unsigned kNullCell = 0xFFFFFFFFu;
 constexpr int kItemMax = 8192;                             // tile kernel: records per work item (held in registers while they are ranked)
@@ -207,18 +208,16 @@ k_b16_scan(int nbins, unsigned item_records, const unsigned* __restrict__ cnt, u
 }
 
 // ---- pass B: records straight from registers -------------------------------------------------------------------
-// THREADS: 1024 (one workgroup per CU), or 512: two workgroups per CU, one's loads and stores behind the other's ranking
-// and reservations, at half the chunk.
-template <class Maker, int THREADS>
-__global__ void __launch_bounds__(THREADS, 4)          // <= 128 VGPRs: two 512-thread workgroups per CU
+template <class Maker>
+__global__ void __launch_bounds__(kScatThreads, 4)     // <= 128 VGPRs: two 512-thread workgroups per CU
 k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, const double* __restrict__ y,
               const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor, uint4* __restrict__ records,
               unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count) {
     extern __shared__ unsigned lds_hist[];                  // [nbins]: rank counters, then the run's global start
-    for (int i = threadIdx.x; i < b.nbins; i += THREADS) lds_hist[i] = 0;
+    for (int i = threadIdx.x; i < b.nbins; i += kScatThreads) lds_hist[i] = 0;
     __syncthreads();
     constexpr int kScatPer = Maker::kPer;                    // points per thread: what the Maker's arithmetic leaves registers for
-    const uint64_t base = (uint64_t)blockIdx.x * (THREADS * kScatPer);
+    const uint64_t base = (uint64_t)blockIdx.x * (kScatThreads * kScatPer);
     uint4 rec[kScatPer];                                     // .x = bin << 16 | local cell until the store
     unsigned rank[kScatPer];
     // every load of the chunk is issued before the first point is routed: one memory latency per workgroup instead of
@@ -232,7 +231,7 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
         typename Maker::Chan ch[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const uint64_t i = base + (uint64_t)(k0 + u) * THREADS + threadIdx.x;
+            const uint64_t i = base + (uint64_t)(k0 + u) * kScatThreads + threadIdx.x;
             const uint64_t ic = i < n ? i : n - 1;
             // read once here: streamed past the caches, which hold the record lines being filled
             wx[u] = __builtin_nontemporal_load(x + ic);
@@ -243,7 +242,7 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int k = k0 + u;
-            const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
+            const uint64_t i = base + (uint64_t)k * kScatThreads + threadIdx.x;
             rec[k] = make_uint4(kNullCell, 0u, 0u, 0u);
             rank[k] = 0xFFFFFFFFu;                           // no slot
             if (i >= n) continue;
@@ -258,22 +257,25 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
     __syncthreads();
     {
         unsigned* mine = cursor + (size_t)(blockIdx.x & (kVx - 1)) * b.nbins;
-        constexpr int kRes = 4;                              // a lane's reservations are issued back to back
-        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * THREADS) {
+        // a lane's reservations are issued back to back, eight at a time: a returning global atomic takes microseconds
+        // under load, and at 16 384 tiles a lane owns 32 of them -- eight rounds of four were ~24 us of pure latency per
+        // workgroup, more than its loads and stores together
+        constexpr int kRes = 8;
+        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * kScatThreads) {
             unsigned c[kRes], gp[kRes];
 #pragma unroll
             for (int u = 0; u < kRes; ++u) {
-                const int i = i0 + u * THREADS;
+                const int i = i0 + u * kScatThreads;
                 c[u] = i < b.nbins ? lds_hist[i] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < kRes; ++u) {
                 gp[u] = 0;
-                if (c[u]) gp[u] = atomicAdd(&mine[i0 + u * THREADS], c[u]);
+                if (c[u]) gp[u] = atomicAdd(&mine[i0 + u * kScatThreads], c[u]);
             }
 #pragma unroll
             for (int u = 0; u < kRes; ++u)
-                if (c[u]) lds_hist[i0 + u * THREADS] = gp[u];
+                if (c[u]) lds_hist[i0 + u * kScatThreads] = gp[u];
         }
     }
     __syncthreads();
@@ -324,12 +326,16 @@ inline int max_bins(const pcr_hip_engine* e) {
     return e->max_bins == kMaxBins ? 16384 : e->max_bins;
 }
 
+// What the scatter pass spends its time on (ablation on 50 M points into 14 555 tiles, profiles/r03_b16_scatter.md):
+// loads + routing + ranking 0.25 ms, the per-(workgroup, tile) reservations 0.12, the 0.8 GB of records as coalesced
+// stores would add 0.09 -- and the fact that every record is its own 16-byte store into a different 128-byte line adds
+// 0.39: 50 M store requests, whatever their size.  Runs only get longer with fewer tiles, and the tile kernels want
+// their records in LDS: that trade is the path's remaining cost.
 // Workgroup size of the scatter pass: 512 -- two workgroups per CU, one's loads and stores behind the other's ranking and
-// reservations (measured, 50 M points: 0.69 vs 0.86 ms at 7 313 tiles, 0.62 vs 0.91 at 3 249, 0.80 vs 0.89 at 16 384;
-// PCR_HIP_B16_THREADS = 1024 selects one workgroup per CU for A/B runs).
-inline int scatter_threads(const pcr_hip_engine* e) { return e->b16_threads == 1024 ? 1024 : 512; }
+// reservations (measured against one 1024-thread workgroup per CU, 50 M points: 0.69 vs 0.86 ms at 7 313 tiles, 0.62 vs
+// 0.91 at 3 249, 0.80 vs 0.89 at 16 384).
 template <class Maker>
-inline int chunk_of(const pcr_hip_engine* e) { return scatter_threads(e) * Maker::kPer; }
+inline int chunk_of() { return kScatThreads * Maker::kPer; }
 
 // The three passes for the points gd owns (a band: the engine's grid with the owned rows narrowed).  The engine's
 // scratch must already hold L.end bytes.
@@ -338,10 +344,9 @@ int bin(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const Maker& mk,
         const float* v, uint64_t n, unsigned item_records, const Layout& L, Buffers* out) {
     char* s = e->d_scratch;
     auto U = [&](size_t o) { return reinterpret_cast<unsigned*>(s + o); };
-    const int threads = scatter_threads(e);
-    const int chunk = threads * Maker::kPer;
-    static_assert((512 * Maker::kPer) % 1024 == 0 && Maker::kPer % 4 == 0, "chunk shape");
-    if (b.chunk != chunk) return fail(PCR_HIP_INVALID_ARGUMENT, "bin16: BinGeom.chunk must be b16::chunk_of<Maker>(e)");
+    constexpr int chunk = kScatThreads * Maker::kPer;
+    static_assert(chunk % 1024 == 0 && Maker::kPer % 4 == 0, "chunk shape");
+    if (b.chunk != chunk) return fail(PCR_HIP_INVALID_ARGUMENT, "bin16: BinGeom.chunk must be b16::chunk_of<Maker>()");
     const int blocks = (int)((n + chunk - 1) / chunk);
     const size_t lds = (size_t)b.nbins * 4;
     PCR_HIP_TRY(hipMemsetAsync(U(L.o_cnt), 0, (size_t)kVx * b.nbins * 4, e->stream));
@@ -366,11 +371,10 @@ int bin(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const Maker& mk,
         ScopedKernelTimer t(e, "k_b16_scatter");
         auto go = [&](auto kernel) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, e->stream, gd, b, mk, x, y, v, n,
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kScatThreads), lds, e->stream, gd, b, mk, x, y, v, n,
                                U(L.o_cursor), reinterpret_cast<uint4*>(s + L.o_rec), U(L.o_fbl), U(L.o_fbc));
         };
-        if (threads == 512) go(&k_b16_scatter<Maker, 512>);
-        else go(&k_b16_scatter<Maker, 1024>);
+        go(&k_b16_scatter<Maker>);
     }
     PCR_HIP_TRY(hipGetLastError());
     out->records = reinterpret_cast<const uint4*>(s + L.o_rec);

@@ -183,14 +183,7 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
         if (v >= 1 && v < kMaxBins) e->max_bins = v;
     }
     if (const char* dbg = std::getenv("PCR_HIP_DEBUG_TWO_LEVEL")) e->two_level = std::atoi(dbg) != 0;
-    if (const char* t = std::getenv("PCR_HIP_ONE_PASS")) e->one_pass = std::atoi(t) != 0;
-    if (const char* t = std::getenv("PCR_HIP_CELL_TILES")) e->cell_tiles = std::atoi(t) != 0;
-    if (const char* t = std::getenv("PCR_HIP_B16_THREADS")) e->b16_threads = std::atoi(t);
-    if (const char* t = std::getenv("PCR_HIP_TUNE_SCATTER")) e->tune_scatter = std::atoi(t);
-    if (const char* t = std::getenv("PCR_HIP_TUNE_B")) e->tune_b = std::atoi(t);
-    if (const char* t = std::getenv("PCR_HIP_TUNE_MOM")) e->tune_mom = std::atoi(t);
     if (const char* t = std::getenv("PCR_HIP_TUNE_CONV")) e->tune_conv = std::atoi(t);
-    if (const char* t = std::getenv("PCR_HIP_TUNE_REC")) e->tune_rec = std::atoi(t);
     hipError_t err = hipGetDevice(&e->device);
     hipDeviceProp_t prop;
     if (err == hipSuccess) err = hipGetDeviceProperties(&prop, e->device);
@@ -396,7 +389,7 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: binned path forced but not applicable");
     if (e->forced_path == 1 || !can_bin) return direct_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
-    if (e->cell_tiles && cells_gauss_supported(e, gl, plane_mask)) rc = cells_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+    if (cells_gauss_supported(e, gl, plane_mask)) rc = cells_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
     else rc = binned_glyph(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
     release_scratch(e);
     return rc;

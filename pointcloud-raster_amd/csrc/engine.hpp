@@ -20,16 +20,10 @@ struct pcr_hip_engine {
     int forced_path = 0;                       // 0 auto, 1 direct, 2 binned, 3 moments (Gaussian only)
     int max_bins = 0;                          // LDS tiles per binning pass (kMaxBins; PCR_HIP_DEBUG_MAX_BINS lowers it
                                                // so that tests reach the large-grid paths on small grids)
-    int tune_scatter = 0;                      // PCR_HIP_TUNE_SCATTER=3: round 1's k_bin_scatter shape (experiments only)
     int stats_scatter_chunk = 0;               // points per k_bin_scatter workgroup of the last binned scatter
-    int tune_rec = 0;                          // PCR_HIP_TUNE_REC: k_rec_scatter chunk shape (experiments only)
-    int tune_conv = 0;                         // PCR_HIP_TUNE_CONV=1: moment path convolutions on the vector ALU (experiments only)
-    int tune_mom = 0;                          // PCR_HIP_TUNE_MOM: k_tile_moments split / store kind (experiments only)
-    int tune_b = 0;                            // PCR_HIP_TUNE_B=1: print k_bin_scatter's phase cycles (experiments only; synchronizes)
-    bool one_pass = false;                     // PCR_HIP_ONE_PASS=1: sampled-provisioning one-pass sort for the Point glyph (opt-in)
+    int tune_conv = 0;                         // PCR_HIP_TUNE_CONV=1 / 2: force the vector-ALU / matrix-core column pass of the moment
+                                               // path (tests reach both kernels on small shapes)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
-    int b16_threads = 512;                     // PCR_HIP_B16_THREADS: workgroup size of the 16-byte-record scatter pass (experiments)
-    bool cell_tiles = true;                    // PCR_HIP_CELL_TILES=0: small Gaussians on round 2's index-record tiles (A/B runs)
     pcr_hip_scatter_stats stats{};
     bool planes_fresh = false;                 // pcr_hip_engine_planes_fresh: the NEXT scatter's planes hold identity values
 
@@ -85,14 +79,8 @@ constexpr int kMaxBands = 32;           // a grid with more LDS tiles than kMaxB
 struct BinItem {                        // one workgroup's share of a bin's records
     unsigned bin, first, count, shared; // shared != 0: the bin was split, merge with atomics
 };
-struct GlyphRec {                       // glyph paths: everything a footprint needs, so that tiles never gather by index
-    double x, y;
-    float v, c0, c1, c2;                // value; per-point channels (GlyphChan)
-};
-static_assert(sizeof(GlyphRec) == 32, "glyph records are two 16-byte halves");
 struct BinBuffers {                     // device pointers into the engine's scratch arena
     const uint2* records;               // Value / Index records, grouped by bin; .x = local cell
-    const GlyphRec* grecords;           // glyphs: grouped by bin
     const BinItem* items;
     const unsigned* n_items;
     int max_items;
@@ -115,9 +103,9 @@ inline int band_rows_for(const GridDev& g, int tile_w, int tile_h, int max_bins)
 // Passes A (histogram + routing keys), scan, B (LDS-staged scatter) over the points that gd owns (for a band:
 // the engine's grid with the owned rows narrowed to the band).  Record kinds:
 //   Value  8 B {local cell, value}         Point glyph
-//   Index  8 B {local cell, point index}   Gaussian tiles (LDS-atomic bound: gathering x, y, v by index hides behind it)
-//   Glyph  32 B GlyphRec                   Line tiles (the gather was their whole run time), needs gl
-enum class RecordKind { Value, Index, Glyph };
+//   Index  8 B {local cell, point index}   Gaussian tiles with per-point sigma / rotation channels or r > 3 (the others, and
+//                                          Lines, bin 16-byte value records: bin16.hpp)
+enum class RecordKind { Value, Index };
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
                uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out);
 

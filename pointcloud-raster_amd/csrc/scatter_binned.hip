@@ -196,16 +196,7 @@ k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_co
 template <int THREADS, int PER_THREAD, int WINDOW, bool VEC, bool INDEX>
 __device__ __forceinline__ void
 bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const unsigned* __restrict__ keys,
-                  const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records,
-                  unsigned long long* __restrict__ prof) {
-    // prof != nullptr (PCR_HIP_TUNE_B=1, experiments only): shader-clock cycles per phase, summed over blocks
-    unsigned long long tprev = prof ? clock64() : 0ull;
-    auto mark = [&](int phase) {
-        if (!prof) return;
-        const unsigned long long t = clock64();
-        if (threadIdx.x == 0) atomicAdd(&prof[phase], t - tprev);
-        tprev = t;
-    };
+                  const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
     // layout: stage[window] (8 B each) | hist[nbins] | loff[nbins]; after the reservation hist[bin] holds
     // (global start of the block's run) - loff[bin], so that the record at sorted position j goes to hist[bin] + j
     uint2* stage = reinterpret_cast<uint2*>(lds_raw);
@@ -242,7 +233,6 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
         if (key[k] != 0xFFFFFFFFu) pos[k] = atomicAdd(&hist[key[k] >> gshift], 1u);       // rank inside (block, bin)
     }
     __syncthreads();
-    mark(0);                                               // load + rank
 
     // block-wide exclusive scan of the bin counts -> loff (thread t owns the consecutive bins [t*per, (t+1)*per))
     const int per = (b.nbins + THREADS - 1) / THREADS;
@@ -267,7 +257,6 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
     unsigned total = 0;
     for (int w = 0; w < kWaves; ++w) total += wave_tot[w];
     __syncthreads();
-    mark(1);                                               // scan
 
     if (VEC) {
         const uint4* v4 = reinterpret_cast<const uint4*>(v + base);
@@ -321,7 +310,6 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
     for (int k = 0; k < PER_THREAD; ++k)
         if (key[k] != 0xFFFFFFFFu) pos[k] += loff[key[k] >> gshift];
     // (the barrier that orders the reservations before the write-out is the one after the first staging round)
-    mark(2);                                               // reserve
 
     for (unsigned w0 = 0; w0 < total; w0 += WINDOW) {
         // stage the records of this window, grouped by bin
@@ -331,7 +319,6 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
             if (key[k] != 0xFFFFFFFFu && rel < (unsigned)WINDOW) stage[rel] = make_uint2(key[k], val[k]);
         }
         __syncthreads();
-        mark(3);                                           // stage
         // write out: consecutive staged records of a bin go to consecutive global slots
         const unsigned cnt = min((unsigned)WINDOW, total - w0);
         for (unsigned j = threadIdx.x; j < cnt; j += THREADS) {
@@ -341,7 +328,6 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
             records[dst] = make_uint2(b.sup_shift ? rec.x : rec.x & kLcellMask, rec.y);   // first of two levels: keep the tile
         }
         __syncthreads();
-        mark(4);                                           // write out
     }
 }
 
@@ -350,391 +336,35 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
 template <int THREADS, int PER_THREAD, int WINDOW, bool INDEX>
 __global__ void __launch_bounds__(THREADS, 4)          // <= 128 VGPRs
 k_bin_scatter(BinGeom b, unsigned full_blocks, const unsigned* __restrict__ keys, const float* __restrict__ v,
-              uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records,
-              unsigned long long* __restrict__ prof) {
+              uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
     extern __shared__ unsigned char lds_dyn[];
     if (blockIdx.x < full_blocks) {
         bin_scatter_chunk<THREADS, PER_THREAD, WINDOW, true, INDEX>(lds_dyn, b, (uint64_t)blockIdx.x * (THREADS * PER_THREAD), keys, v, n,
-                                                                    cursor, records, prof);
+                                                                    cursor, records);
     } else {
         const uint64_t base = (uint64_t)full_blocks * (THREADS * PER_THREAD) + (uint64_t)(blockIdx.x - full_blocks) * 4096;
-        bin_scatter_chunk<THREADS, 4096 / THREADS, WINDOW, false, INDEX>(lds_dyn, b, base, keys, v, n, cursor, records, prof);
+        bin_scatter_chunk<THREADS, 4096 / THREADS, WINDOW, false, INDEX>(lds_dyn, b, base, keys, v, n, cursor, records);
     }
 }
 
-// One launcher for both users (single-level binning and the first level of the two-level sort).
-struct ScatterShape { int threads, per, window; };
-inline ScatterShape scatter_shape(const pcr_hip_engine* e, const BinGeom& b) {
-    // PCR_HIP_TUNE_SCATTER=3 (experiments only): round 1's shape, the whole 16384 / 8192-point chunk staged at once
-    if (e->tune_scatter == 3) return b.chunk == 16384 ? ScatterShape{1024, 16, 16384} : ScatterShape{1024, 8, 8192};
-    return {1024, 28, 8192};
-}
-
+// One launcher for both users (single-level binning and the first level of the two-level sort): 1024 threads x 28 points,
+// 64 KB staging window (the shape profiles/r02_tune_scatter.md settled on).
 template <bool INDEX>
 void launch_bin_scatter(pcr_hip_engine* e, const BinGeom& b, const unsigned* d_keys, const float* v, uint64_t n,
                         unsigned* d_cursor, uint2* d_rec) {
-    const ScatterShape sh = scatter_shape(e, b);
-    const uint64_t chunk = (uint64_t)sh.threads * sh.per;
-    const int blocks = (int)((n + chunk - 1) / chunk);
+    constexpr int kT = 1024, kPer = 28, kWindow = 8192;
+    const uint64_t chunk = (uint64_t)kT * kPer;
     const bool aligned = INDEX || (reinterpret_cast<uintptr_t>(v) & 15) == 0;     // d_keys is 256-B aligned
     const int full_blocks = aligned ? (int)(n / chunk) : 0;
-    const size_t lds = (size_t)sh.window * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
-    unsigned long long* d_prof = nullptr;
-    if (e->tune_b == 1 && hipMalloc(reinterpret_cast<void**>(&d_prof), 8 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), e->stream);
+    const size_t lds = (size_t)kWindow * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
     const uint64_t done = (uint64_t)full_blocks * chunk;
-    const unsigned tail_blocks = (unsigned)((n - done + 4095) / 4096);     // every shape's chunk is a multiple of 4096
-    auto launch = [&](auto kernel, int threads) {
-        ScopedKernelTimer t(e, "k_bin_scatter");
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)full_blocks + tail_blocks), dim3(threads), lds, e->stream, b, (unsigned)full_blocks,
-                           d_keys, v, n, d_cursor, d_rec, d_prof);
-    };
-    if (sh.threads == 1024 && sh.per == 28 && sh.window == 8192) launch(&k_bin_scatter<1024, 28, 8192, INDEX>, 1024);
-    else if (sh.threads == 1024 && sh.per == 16 && sh.window == 16384) launch(&k_bin_scatter<1024, 16, 16384, INDEX>, 1024);
-    else launch(&k_bin_scatter<1024, 8, 8192, INDEX>, 1024);
+    const unsigned tail_blocks = (unsigned)((n - done + 4095) / 4096);            // the chunk is a multiple of 4096
+    ScopedKernelTimer t(e, "k_bin_scatter");
+    auto kernel = &k_bin_scatter<kT, kPer, kWindow, INDEX>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)full_blocks + tail_blocks), dim3(kT), lds, e->stream, b, (unsigned)full_blocks,
+                       d_keys, v, n, d_cursor, d_rec);
     e->stats_scatter_chunk = (int)chunk;
-    if (d_prof) {                                          // experiments only: synchronizes
-        unsigned long long h[8] = {0};
-        (void)hipStreamSynchronize(e->stream);
-        (void)hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost);
-        (void)hipFree(d_prof);
-        std::fprintf(stderr, "k_bin_scatter<%d,%d,%d> cycles per block: load+rank %.0f scan %.0f reserve %.0f stage %.0f write %.0f\n",
-                     sh.threads, sh.per, sh.window, (double)h[0] / blocks, (double)h[1] / blocks, (double)h[2] / blocks,
-                     (double)h[3] / blocks, (double)h[4] / blocks);
-    }
-}
-
-// ================================================================================================================
-// ONE-PASS binning for the Point glyph: sampled provisioning instead of a counting pass.
-//
-// The two-pass sort above reads x, y once to COUNT (and parks a 4-byte routing key per point), then reads keys +
-// values to SCATTER: 16 R + 4 W + 8 R + 8 W = 36 bytes per point, and the counting pass is a third of the step.
-// A counting sort needs the bin sizes only to know where each bin's run starts.  Here the starts come from an
-// ESTIMATE: one 64-point granule in sixteen is routed and counted (k_bin_sample: 1 byte per point of traffic),
-// every bin is provisioned for 16 x its sample count plus a margin (k_bin_provision: +1/8 + 32 sqrt + 2048 records,
-// > 6 sigma for clouds in any order, and still enough when the cloud is sorted by tile and a bin is a few hundred
-// consecutive granules), and ONE pass routes, ranks and scatters the points (k_bin_scatter1: 20 R + 8 W bytes per
-// point).  Exactness does not depend on the estimate: a (block, bin) run reserves its place with the same atomic as
-// before, and whatever does not fit the bin's provision goes -- key and value -- to an overflow list that a small
-// kernel folds into the planes with global atomics after the tile pass (k_ovf_apply; normally empty).  Work items
-// are cut from the ACTUAL counts afterwards (k_prov_items).  PCR_HIP_DEBUG_PROVISION=<percent> scales the
-// provisions (tests force the overflow path with it).
-//
-// Status: OPT-IN (PCR_HIP_ONE_PASS=1), parity-green (tests/test_gpu_one_pass.py).  Measured on MI355X, C2 (50 M points,
-// 4096^2): HBM traffic of the binning drops from 1.87 GB (count 1.02 + scatter 0.85) to 1.50 GB (sample 0.05 + scatter
-// 1.45), the whole step from 2.28x to 1.97x its algorithmic bytes -- but the step takes the same 0.70 ms: one workgroup
-// per CU now does the routing arithmetic, the ranking and the partial-line record writes back to back (k_bin_scatter1
-// 0.45 ms at 3.2 TB/s; two 512-thread workgroups per CU, all loads up front, 64-byte aligned runs: no gain), where the
-// two-pass form streams its counting pass at 4.5 TB/s with three workgroups per CU.  Less traffic for the same time
-// is not worth being the default; it stays selectable for HBM-contended settings.
-constexpr int kOpThreads = 1024;
-constexpr int kOpPairs = 14;                          // 16-byte loads of x (and of y) per thread: two points each
-constexpr int kOpPer = 2 * kOpPairs;                  // 28 points per thread
-constexpr int kOpWindow = 8192;                       // staging window, records
-constexpr int kSampleStride = 16;                     // one 64-point granule in 16 is counted
-constexpr int kOpMaxBins = 4096;                      // LDS: 64 KB window + 12 B per bin
-
-__global__ void __launch_bounds__(1024)
-k_bin_sample(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y, uint64_t n,
-             unsigned* __restrict__ sample_count) {
-    extern __shared__ unsigned lds_hist[];
-    for (int i = threadIdx.x; i < b.nbins; i += 1024) lds_hist[i] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t granules = (n + 63) / 64, sampled = (granules + kSampleStride - 1) / kSampleStride;
-    for (uint64_t sidx = (uint64_t)blockIdx.x * 16 + wave; sidx < sampled; sidx += (uint64_t)gridDim.x * 16) {
-        const uint64_t i = sidx * kSampleStride * 64 + lane;
-        if (i < n) {
-            Routed r = route(g, b, x[i], y[i]);
-            if (r.valid && point_kept(g, i)) atomicAdd(&lds_hist[r.bin], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < b.nbins; i += 1024) {
-        const unsigned c = lds_hist[i];
-        if (c) atomicAdd(&sample_count[i], c);
-    }
-}
-
-// provisions -> bin starts; cursors zeroed (they count records relative to the bin's start)
-__global__ void __launch_bounds__(kThreads)
-k_bin_provision(int nbins, int percent, const unsigned* __restrict__ sample_count, unsigned* __restrict__ cap,
-                unsigned* __restrict__ start, unsigned* __restrict__ cursor) {
-    __shared__ unsigned part[kThreads];
-    const int per = (nbins + kThreads - 1) / kThreads;
-    const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
-    unsigned s = 0;
-    for (int i = lo; i < hi; ++i) {
-        const unsigned c = sample_count[i] * kSampleStride;
-        unsigned cp = c + c / 8 + (unsigned)(32.0f * sqrtf((float)c)) + 2048u;
-        if (percent != 100) cp = (unsigned)((unsigned long long)cp * (unsigned)percent / 100u);
-        cap[i] = cp;
-        s += cp;
-    }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const unsigned a = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += a;
-        __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; ++i) {
-        start[i] = run;
-        cursor[i] = 0u;
-        run += cap[i];
-    }
-    if (threadIdx.x == kThreads - 1) start[nbins] = part[threadIdx.x];
-}
-
-// One chunk of THREADS x PER_THREAD points.  VEC: a full chunk, x / y 16-byte and v 8-byte aligned (two points per
-// load); otherwise scalar loads with bounds checks (the ragged end of the cloud, or unaligned arrays).
-template <int THREADS, int PER_THREAD, int WINDOW, bool VEC>
-__device__ __forceinline__ void
-scatter1_chunk(unsigned char* lds_raw, const GridDev& g, const BinGeom& b, uint64_t base, const double* __restrict__ x,
-               const double* __restrict__ y, const float* __restrict__ v, uint64_t n, const unsigned* __restrict__ cap,
-               const unsigned* __restrict__ start, unsigned* __restrict__ cursor, uint2* __restrict__ records,
-               uint2* __restrict__ ovf, unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ touched,
-               unsigned long long* __restrict__ counters) {
-    // layout: stage[window] (8 B each) | hist[nbins] | loff[nbins] | okc[nbins]
-    uint2* stage = reinterpret_cast<uint2*>(lds_raw);
-    unsigned* hist = reinterpret_cast<unsigned*>(lds_raw + (size_t)WINDOW * sizeof(uint2));
-    unsigned* loff = hist + b.nbins;
-    unsigned* okc = loff + b.nbins;
-    constexpr int kWaves = THREADS / 64;
-    __shared__ unsigned wave_tot[kWaves];
-    __shared__ unsigned blk_valid, blk_ovf, ovf_ctr;
-    __shared__ unsigned long long ovf_base;
-
-    for (int i = threadIdx.x; i < b.nbins; i += THREADS) hist[i] = 0;
-    if (threadIdx.x == 0) { blk_valid = 0; blk_ovf = 0; ovf_ctr = 0; }
-    __syncthreads();
-    const bool one_tile = g.tiles_x * g.tiles_y == 1;
-
-    // ---- route + rank: x, y are consumed here and never held
-    unsigned key[PER_THREAD], pos[PER_THREAD], val[PER_THREAD];
-    unsigned my_valid = 0;
-    auto take = [&](int k, uint64_t i, double wx, double wy) {
-        key[k] = 0xFFFFFFFFu;
-        pos[k] = 0;
-        Routed r = route(g, b, wx, wy);
-        if (i < n && r.valid && point_kept(g, i)) {
-            key[k] = ((unsigned)r.bin << kLcellBits) | r.lcell;
-            pos[k] = atomicAdd(&hist[r.bin], 1u);
-            ++my_valid;
-            if (!one_tile) touch_tile(g, touched, r.row, r.col);
-        }
-    };
-    if (VEC) {
-        const double2* x2 = reinterpret_cast<const double2*>(x + base);
-        const double2* y2 = reinterpret_cast<const double2*>(y + base);
-        constexpr int kBatch = PER_THREAD / 2;             // every load of the chunk in flight before the first point is routed
-#pragma unroll
-        for (int q0 = 0; q0 < PER_THREAD / 2; q0 += kBatch) {
-            double2 xs[kBatch], ys[kBatch];
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                xs[u] = x2[(q0 + u) * THREADS + threadIdx.x];
-                ys[u] = y2[(q0 + u) * THREADS + threadIdx.x];
-            }
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const uint64_t i = base + 2ull * ((q0 + u) * THREADS + threadIdx.x);
-                take(2 * (q0 + u), i, xs[u].x, ys[u].x);
-                take(2 * (q0 + u) + 1, i + 1, xs[u].y, ys[u].y);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < PER_THREAD; ++k) {
-            const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
-            const uint64_t ic = i < n ? i : n - 1;
-            take(k, i, x[ic], y[ic]);
-        }
-    }
-    if (my_valid) atomicAdd(&blk_valid, my_valid);
-    __syncthreads();
-
-    // ---- block-wide exclusive scan of the bin counts -> loff
-    const int per = (b.nbins + THREADS - 1) / THREADS;
-    const int lo = threadIdx.x * per, hi = min(lo + per, b.nbins);
-    unsigned s = 0;
-    for (int i = lo; i < hi; ++i) s += hist[i];
-    unsigned incl = s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned run = incl - s;
-    for (int w = 0; w < wave; ++w) run += wave_tot[w];
-    for (int i = lo; i < hi; ++i) {
-        loff[i] = run;
-        run += hist[i];
-    }
-    unsigned total = 0;
-    for (int w = 0; w < kWaves; ++w) total += wave_tot[w];
-    __syncthreads();
-
-    // ---- values: issued now, complete behind the reservation atomics
-    if (VEC) {
-        const float2* v2 = reinterpret_cast<const float2*>(v + base);
-#pragma unroll
-        for (int q = 0; q < PER_THREAD / 2; ++q) {
-            const float2 vv = v ? v2[q * THREADS + threadIdx.x] : make_float2(0.f, 0.f);
-            val[2 * q] = __float_as_uint(vv.x);
-            val[2 * q + 1] = __float_as_uint(vv.y);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < PER_THREAD; ++k) {
-            const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
-            val[k] = (v && i < n) ? __float_as_uint(v[i]) : 0u;
-        }
-    }
-
-    // ---- reservations: bins dealt to lanes interleaved, atomics back to back; what exceeds the provision overflows
-    {
-        constexpr int kRes = 4;
-        unsigned my_ovf = 0;
-        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * THREADS) {
-            unsigned c[kRes], got[kRes];
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                const int i = i0 + u * THREADS;
-                c[u] = i < b.nbins ? hist[i] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                got[u] = 0;
-                if (c[u]) got[u] = atomicAdd(&cursor[i0 + u * THREADS], c[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                const int i = i0 + u * THREADS;
-                if (i >= b.nbins) continue;
-                unsigned ok = 0;
-                if (c[u]) {
-                    const unsigned cp = cap[i];
-                    ok = got[u] >= cp ? 0u : min(c[u], cp - got[u]);
-                    hist[i] = start[i] + got[u] - loff[i];      // record at sorted position j -> hist[bin] + j
-                    my_ovf += c[u] - ok;
-                }
-                okc[i] = ok;
-            }
-        }
-        if (my_ovf) { atomicAdd(&ovf_ctr, my_ovf); blk_ovf = 1u; }
-    }
-#pragma unroll
-    for (int k = 0; k < PER_THREAD; ++k)
-        if (key[k] != 0xFFFFFFFFu) pos[k] += loff[key[k] >> kLcellBits];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (blk_valid) {
-            atomicAdd(counters, (unsigned long long)blk_valid);
-            if (one_tile) touched[0] = 1u;
-        }
-        if (blk_ovf) {
-            ovf_base = atomicAdd(ovf_count, (unsigned long long)ovf_ctr);
-            ovf_ctr = 0;
-        }
-    }
-    __syncthreads();
-    const bool spill = blk_ovf != 0;
-
-    for (unsigned w0 = 0; w0 < total; w0 += WINDOW) {
-#pragma unroll
-        for (int k = 0; k < PER_THREAD; ++k) {
-            const unsigned rel = pos[k] - w0;                  // wraps for positions before the window
-            if (key[k] != 0xFFFFFFFFu && rel < (unsigned)WINDOW) stage[rel] = make_uint2(key[k], val[k]);
-        }
-        __syncthreads();
-        const unsigned cnt = min((unsigned)WINDOW, total - w0);
-        for (unsigned j = threadIdx.x; j < cnt; j += THREADS) {
-            const uint2 rec = stage[j];
-            const unsigned bin = rec.x >> kLcellBits;
-            if (!spill || (w0 + j - loff[bin]) < okc[bin]) {
-                records[hist[bin] + w0 + j] = make_uint2(rec.x & kLcellMask, rec.y);
-            } else {
-                ovf[ovf_base + atomicAdd(&ovf_ctr, 1u)] = rec;            // keeps the bin: folded with global atomics later
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// Blocks [0, full_blocks) take a full 28672-point chunk each; the blocks after them share the ragged end of the cloud in
-// 4096-point chunks through the scalar-load body -- one launch (a second, tiny launch cost 10-17 us of pure latency).
-template <int THREADS, int PER_THREAD, int WINDOW>
-__global__ void __launch_bounds__(THREADS, 4)
-k_bin_scatter1(GridDev g, BinGeom b, unsigned full_blocks, const double* __restrict__ x, const double* __restrict__ y,
-               const float* __restrict__ v, uint64_t n, const unsigned* __restrict__ cap, const unsigned* __restrict__ start,
-               unsigned* __restrict__ cursor, uint2* __restrict__ records, uint2* __restrict__ ovf,
-               unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ touched,
-               unsigned long long* __restrict__ counters) {
-    extern __shared__ unsigned char lds_dyn[];
-    constexpr int kTailPer = 4096 / THREADS;
-    if (blockIdx.x < full_blocks) {
-        scatter1_chunk<THREADS, PER_THREAD, WINDOW, true>(lds_dyn, g, b, (uint64_t)blockIdx.x * (THREADS * PER_THREAD), x, y, v, n,
-                                                          cap, start, cursor, records, ovf, ovf_count, touched, counters);
-    } else {
-        const uint64_t base = (uint64_t)full_blocks * (THREADS * PER_THREAD) + (uint64_t)(blockIdx.x - full_blocks) * 4096;
-        scatter1_chunk<THREADS, kTailPer, WINDOW, false>(lds_dyn, g, b, base, x, y, v, n, cap, start, cursor, records, ovf,
-                                                         ovf_count, touched, counters);
-    }
-}
-
-// work items from the ACTUAL counts (cursor, clipped to the provision); bin starts are the provisioned ones
-__global__ void __launch_bounds__(kThreads)
-k_prov_items(int nbins, unsigned item_records, const unsigned* __restrict__ start, const unsigned* __restrict__ cap,
-             const unsigned* __restrict__ cursor, BinItem* __restrict__ items, unsigned* __restrict__ n_items) {
-    __shared__ unsigned ipart[kThreads];
-    const int per = (nbins + kThreads - 1) / kThreads;
-    const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
-    unsigned it = 0;
-    for (int i = lo; i < hi; ++i) it += (min(cursor[i], cap[i]) + item_records - 1) / item_records;
-    ipart[threadIdx.x] = it;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const unsigned a = (int)threadIdx.x >= off ? ipart[threadIdx.x - off] : 0u;
-        __syncthreads();
-        ipart[threadIdx.x] += a;
-        __syncthreads();
-    }
-    unsigned irun = ipart[threadIdx.x] - it;
-    for (int i = lo; i < hi; ++i) {
-        const unsigned c = min(cursor[i], cap[i]);
-        const unsigned pieces = (c + item_records - 1) / item_records;
-        for (unsigned q = 0; q < pieces; ++q)
-            items[irun + q] = BinItem{(unsigned)i, start[i] + q * item_records, min(item_records, c - q * item_records),
-                                      pieces > 1 ? 1u : 0u};
-        irun += pieces;
-    }
-    if (threadIdx.x == kThreads - 1) *n_items = ipart[threadIdx.x];
-}
-
-// overflow records {bin << 15 | local cell, value}: straight into the planes with global atomics
-template <unsigned MASK>
-__global__ void __launch_bounds__(256)
-k_ovf_apply(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ ovf, const unsigned long long* __restrict__ ovf_count) {
-    const unsigned long long n = *ovf_count;
-    for (unsigned long long j = (unsigned long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256) {
-        const uint2 rec = ovf[j];
-        const int bin = (int)(rec.x >> kLcellBits), lcell = (int)(rec.x & kLcellMask);
-        const int by = bin / b.bins_x, bx = bin - by * b.bins_x;
-        const int ly = lcell / b.tile_w, lx = lcell - ly * b.tile_w;
-        const int64_t cell = (int64_t)(b.row0 + by * b.tile_h + ly) * g.W + (bx * b.tile_w + lx);
-        const float val = __uint_as_float(rec.y);
-        if (MASK & 1) atomic_add_f32(pl.sum + cell, val);
-        if (MASK & 2) atomic_add_f32(pl.wgt + cell, 1.0f);
-        if (MASK & 4) atomic_max_f32(pl.mx + cell, val);
-        if (MASK & 8) atomic_min_f32(pl.mn + cell, val);
-    }
 }
 
 // ---- second level of the two-level sort (grids with more tiles than one pass can count in LDS) ----
@@ -828,88 +458,6 @@ k_sub_scatter(int sup_shift, const uint2* __restrict__ rec, const BinItem* __res
         const uint2 q = stage[j];
         const unsigned t = (q.x >> kLcellBits) - tile0;
         out[gbase[t] + (j - loff[t])] = make_uint2(q.x & kLcellMask, q.y);
-    }
-}
-
-// ---- pass B for glyphs: 32-byte records {x, y, value, channels}, written straight from registers ----
-// A glyph tile needs the point's exact f64 position and its channels; fetching them by index from the
-// tile kernel costs a 64-byte sector per 4-8 useful bytes (13 GB per 50 M points, measured as the whole
-// run time of k_tile_line).  Here they are read once, coalesced, and travel with the record.  No LDS
-// staging of the data: a lane stores its own record (two 16-byte stores); the records of one (block, bin)
-// run are adjacent in memory and meet in L2.
-// Shape: KEYS keys per thread (a KEYS x 1024-point chunk whatever the bin count, so that a (block, bin) run is a few
-// records long), BATCH records assembled per thread at a time.  A key is kept as bin << 16 | rank-in-the-chunk's-run
-// (one register per point; the local cell is not part of a glyph record).
-template <int THREADS, int KEYS, int BATCH>
-__global__ void __launch_bounds__(THREADS)
-k_rec_scatter(BinGeom b, GlyphDev gl, const unsigned* __restrict__ keys, const double* __restrict__ x,
-              const double* __restrict__ y, const float* __restrict__ v, uint64_t n,
-              unsigned* __restrict__ cursor, GlyphRec* __restrict__ records) {
-    static_assert(KEYS % BATCH == 0 && KEYS * THREADS <= 65536, "chunk shape");
-    extern __shared__ unsigned lds_u32[];
-    unsigned* hist = lds_u32;                   // [nbins]  then reused as the bin's global base
-    for (int i = threadIdx.x; i < b.nbins; i += THREADS) hist[i] = 0;
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * (KEYS * THREADS);
-    const float* ch0 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.sigma_x : gl.direction;
-    const float* ch1 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.sigma_y : gl.half_length;
-    const float* ch2 = gl.type == PCR_HIP_GLYPH_GAUSSIAN ? gl.rotation : nullptr;
-    unsigned kr[KEYS];
-#pragma unroll
-    for (int k = 0; k < KEYS; ++k) {
-        const uint64_t i = base + (uint64_t)k * THREADS + threadIdx.x;
-        kr[k] = i < n ? keys[i] : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int k = 0; k < KEYS; ++k) {
-        if (kr[k] == 0xFFFFFFFFu) continue;
-        const unsigned bin = kr[k] >> kLcellBits;
-        kr[k] = (bin << 16) | atomicAdd(&hist[bin], 1u);
-    }
-    __syncthreads();
-    {
-        constexpr int kRes = 4;                               // a lane's reservations are issued back to back
-        for (int i0 = threadIdx.x; i0 < b.nbins; i0 += kRes * THREADS) {
-            unsigned c[kRes], gp[kRes];
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                const int i = i0 + u * THREADS;
-                c[u] = i < b.nbins ? hist[i] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < kRes; ++u) {
-                gp[u] = 0;
-                if (c[u]) gp[u] = atomicAdd(&cursor[i0 + u * THREADS], c[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < kRes; ++u)
-                if (c[u]) hist[i0 + u * THREADS] = gp[u];  // now: where this block's run of the bin starts
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k0 = 0; k0 < KEYS; k0 += BATCH) {
-        double wx[BATCH], wy[BATCH];
-        float val[BATCH], c0[BATCH], c1[BATCH], c2[BATCH];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {       // the batch's loads in flight before the first store
-            const uint64_t i = base + (uint64_t)(k0 + u) * THREADS + threadIdx.x;
-            const uint64_t ic = i < n ? i : n - 1;
-            wx[u] = x[ic];
-            wy[u] = y[ic];
-            val[u] = v ? v[ic] : 0.f;
-            c0[u] = ch0 ? ch0[ic] : 0.f;
-            c1[u] = ch1 ? ch1[ic] : 0.f;
-            c2[u] = ch2 ? ch2[ic] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const unsigned kk = kr[k0 + u];
-            if (kk == 0xFFFFFFFFu) continue;
-            GlyphRec r;
-            r.x = wx[u]; r.y = wy[u]; r.v = val[u]; r.c0 = c0[u]; r.c1 = c1[u]; r.c2 = c2[u];
-            records[hist[kk >> 16] + (kk & 0xFFFFu)] = r;
-        }
     }
 }
 
@@ -1088,7 +636,7 @@ namespace pcrhip {
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
                uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out) {
     const int max_items = b.nbins + (int)(n / item_records) + 1;
-    const size_t rec_bytes = kind == RecordKind::Glyph ? sizeof(GlyphRec) : sizeof(uint2);
+    const size_t rec_bytes = sizeof(uint2);
 
     size_t off = 0;                                             // scratch carve-up
     const size_t o_count = off;  off += align256((size_t)b.nbins * 4);
@@ -1122,30 +670,11 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, item_records, d_count,
                            d_cursor, d_items, d_nitems);
     }
-    if (kind == RecordKind::Glyph) {
-        ScopedKernelTimer t(e, "k_rec_scatter");
-        GlyphRec* d_rec = reinterpret_cast<GlyphRec*>(s + o_rec);
-        const size_t lds = (size_t)b.nbins * 4;
-        auto launch = [&](auto kernel, int threads, int chunk) {
-            const int rblocks = (int)((n + chunk - 1) / chunk);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(rblocks), dim3(threads), lds, e->stream, b, *gl, d_keys, x, y, v, n, d_cursor, d_rec);
-        };
-        // Shape, measured on MI355X (Line hl=16, 50 M points, 3249 bins; same box, alternating runs, tools/ab_env.sh):
-        // 256 threads x 16 keys with all 16 payload loads in flight (three workgroups per CU)  1.28-1.32 ms;
-        // 1024 x 16 in batches of 8 (one workgroup per CU, the first shape)                     1.36-1.38 ms;
-        // longer chunks (1024 x 24 / 32) are slower, 128-thread groups too.  The kernel's time also moves by +-10 %
-        // from process to process at the same shape (placement of the arrays in HBM).
-        if (e->tune_rec == 1) launch(&k_rec_scatter<1024, 16, 8>, 1024, 16 * 1024);     // experiments: PCR_HIP_TUNE_REC=1
-        else launch(&k_rec_scatter<256, 16, 16>, 256, 16 * 256);
-        out->records = nullptr;
-        out->grecords = d_rec;
-    } else {
+    {
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
         if (kind == RecordKind::Index) launch_bin_scatter<true>(e, b, d_keys, v, n, d_cursor, d_rec);
         else launch_bin_scatter<false>(e, b, d_keys, v, n, d_cursor, d_rec);
         out->records = d_rec;
-        out->grecords = nullptr;
     }
     PCR_HIP_TRY(hipGetLastError());
     out->items = d_items;
@@ -1226,96 +755,10 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     }
     PCR_HIP_TRY(hipGetLastError());
     out->records = d_rec2;
-    out->grecords = nullptr;
     out->items = d_items2;
     out->n_items = U(o_nitems2);
     out->max_items = max_items2;
     return PCR_HIP_OK;
-}
-
-// One-pass binning (sampled provisioning) of the whole window for the Point glyph: see k_bin_scatter1.
-int bin_points_one_pass(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const PlanesDev& pl, uint32_t mask,
-                        const double* x, const double* y, const float* v, uint64_t n, unsigned item_records,
-                        BinBuffers* out, uint2** d_ovf_out, unsigned long long** d_ovf_count_out) {
-    (void)pl; (void)mask;
-    const int op_window = kOpWindow;
-    const uint64_t chunk = (uint64_t)kOpThreads * kOpPer;
-    // upper bound of the sum of the provisions (k_bin_provision): sum c <= n + 1024, sum sqrt(c) <= sqrt(nbins * sum c)
-    const double sum_c = (double)n + 1024.0;
-    const uint64_t rec_cap = (uint64_t)(sum_c + sum_c / 8.0 + 32.0 * std::sqrt((double)b.nbins * sum_c) + 2049.0 * b.nbins) + 64;
-    if (rec_cap >= (1ull << 32)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: too many points for one binning pass");
-    const int max_items = b.nbins + (int)(rec_cap / item_records) + 1;
-
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
-    const size_t o_sample = carve((size_t)b.nbins * 4), o_cap = carve((size_t)b.nbins * 4);
-    const size_t o_start = carve((size_t)(b.nbins + 1) * 4), o_cursor = carve((size_t)b.nbins * 4);
-    const size_t o_nitems = carve(4), o_ovfc = carve(8);
-    const size_t o_items = carve((size_t)max_items * sizeof(BinItem));
-    const size_t o_rec = carve((size_t)rec_cap * sizeof(uint2)), o_ovf = carve((size_t)n * sizeof(uint2));
-    int rc = ensure_scratch(e, off);
-    if (rc) return rc;
-    char* s = e->d_scratch;
-    auto U = [&](size_t o) { return reinterpret_cast<unsigned*>(s + o); };
-    BinItem* d_items = reinterpret_cast<BinItem*>(s + o_items);
-    uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
-    uint2* d_ovf = reinterpret_cast<uint2*>(s + o_ovf);
-    unsigned long long* d_ovfc = reinterpret_cast<unsigned long long*>(s + o_ovfc);
-
-    PCR_HIP_TRY(hipMemsetAsync(U(o_sample), 0, (size_t)b.nbins * 4, e->stream));
-    PCR_HIP_TRY(hipMemsetAsync(d_ovfc, 0, 8, e->stream));
-    {
-        ScopedKernelTimer t(e, "k_bin_sample");
-        const uint64_t sampled = ((n + 63) / 64 + kSampleStride - 1) / kSampleStride;
-        // few, fat blocks: every block flushes a histogram of nbins counters with global atomics
-        const int sblocks = (int)std::min<uint64_t>((sampled + 15) / 16, 256);
-        hipLaunchKernelGGL(k_bin_sample, dim3(sblocks), dim3(1024), (size_t)b.nbins * 4, e->stream, gd, b, x, y, n, U(o_sample));
-    }
-    {
-        ScopedKernelTimer t(e, "k_bin_provision");
-        int percent = 100;
-        if (const char* dbg = std::getenv("PCR_HIP_DEBUG_PROVISION")) {
-            const int pc = std::atoi(dbg);
-            if (pc >= 0 && pc <= 100) percent = pc;               // tests: starve the bins to force the overflow path
-        }
-        hipLaunchKernelGGL(k_bin_provision, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, percent, U(o_sample), U(o_cap),
-                           U(o_start), U(o_cursor));
-    }
-    {
-        const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
-                             (reinterpret_cast<uintptr_t>(v) & 7) == 0;
-        const uint64_t full_blocks = aligned ? n / chunk : 0;
-        const uint64_t done = full_blocks * chunk;
-        const uint64_t tail_blocks = (n - done + 4095) / 4096;
-        ScopedKernelTimer t(e, "k_bin_scatter1");
-        const size_t lds = (size_t)op_window * sizeof(uint2) + (size_t)b.nbins * 4 * 3;
-        auto kernel = &k_bin_scatter1<kOpThreads, kOpPer, kOpWindow>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)(full_blocks + tail_blocks)), dim3(kOpThreads), lds, e->stream, gd, b,
-                           (unsigned)full_blocks, x, y, v, n, U(o_cap), U(o_start), U(o_cursor), d_rec, d_ovf, d_ovfc,
-                           e->d_touched, e->d_counters);
-    }
-    {
-        ScopedKernelTimer t(e, "k_prov_items");
-        hipLaunchKernelGGL(k_prov_items, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, item_records, U(o_start), U(o_cap),
-                           U(o_cursor), d_items, U(o_nitems));
-    }
-    PCR_HIP_TRY(hipGetLastError());
-    e->stats_scatter_chunk = (int)chunk;
-    out->records = d_rec;
-    out->grecords = nullptr;
-    out->items = d_items;
-    out->n_items = U(o_nitems);
-    out->max_items = max_items;
-    *d_ovf_out = d_ovf;
-    *d_ovf_count_out = d_ovfc;
-    return PCR_HIP_OK;
-}
-
-template <unsigned MASK>
-void launch_ovf(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const PlanesDev& pl, const uint2* d_ovf,
-                const unsigned long long* d_ovfc) {
-    hipLaunchKernelGGL((k_ovf_apply<MASK>), dim3(256), dim3(256), 0, e->stream, gd, b, pl, d_ovf, d_ovfc);
 }
 
 // Bands of state rows, each with at most kMaxBins LDS tiles; every band is a full pass over the points
@@ -1364,35 +807,6 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
         nbands = 0;
     } else if (nbands < 1) {
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: grid cannot be binned");
-    } else if (e->one_pass && nbands == 1 && b.nbins <= kOpMaxBins && n >= (1u << 18)) {
-        // opt-in (PCR_HIP_ONE_PASS=1): one window, one level -> the one-pass sort (no counting pass, no routing keys)
-        BinBuffers bb{};
-        uint2* d_ovf = nullptr;
-        unsigned long long* d_ovfc = nullptr;
-        int rc = bin_points_one_pass(e, e->gd, b, pl, mask, x, y, v, n, kPointItemRecords, &bb, &d_ovf, &d_ovfc);
-        if (rc) return rc;
-        {
-            ScopedKernelTimer t(e, "k_tile_accum");
-            switch (mask) {
-#define PCR_ACC(M) case M: launch_accum<M>(e, e->gd, b, pl, bb); break;
-                PCR_ACC(1) PCR_ACC(2) PCR_ACC(3) PCR_ACC(4) PCR_ACC(5) PCR_ACC(6) PCR_ACC(7) PCR_ACC(8)
-                PCR_ACC(9) PCR_ACC(10) PCR_ACC(11) PCR_ACC(12) PCR_ACC(13) PCR_ACC(14) PCR_ACC(15)
-#undef PCR_ACC
-                default: return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: empty plane mask");
-            }
-        }
-        {
-            ScopedKernelTimer t(e, "k_ovf_apply");               // normally an empty list: ~2 us
-            switch (mask) {
-#define PCR_OVF(M) case M: launch_ovf<M>(e, e->gd, b, pl, d_ovf, d_ovfc); break;
-                PCR_OVF(1) PCR_OVF(2) PCR_OVF(3) PCR_OVF(4) PCR_OVF(5) PCR_OVF(6) PCR_OVF(7) PCR_OVF(8)
-                PCR_OVF(9) PCR_OVF(10) PCR_OVF(11) PCR_OVF(12) PCR_OVF(13) PCR_OVF(14) PCR_OVF(15)
-#undef PCR_OVF
-                default: break;
-            }
-        }
-        total_bins = b.nbins;
-        nbands = 0;
     }
     for (int band = 0; band < nbands; ++band) {
         const int row0 = band * band_rows, rows = std::min(band_rows, e->gd.st_rows - row0);

@@ -165,53 +165,6 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
     }
 }
 
-// ---- Line tiles ---------------------------------------------------------------------------------------
-template <unsigned MASK, bool COVERED>
-__global__ void __launch_bounds__(kThreads)
-k_tile_line(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const GlyphRec* __restrict__ records,
-            const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
-    extern __shared__ double lds_win[];
-    if (blockIdx.x >= *n_items) return;
-    const BinItem it = items[blockIdx.x];
-    const int cells = t.lw * t.lh;                           // even (lw, lh even)
-    double* t_s = lds_win;
-    unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
-    for (int i = threadIdx.x; i < cells; i += kThreads) {
-        if (MASK & 1) t_s[i] = 0.0;
-        if (MASK & 2) t_c[i] = 0u;
-    }
-    __syncthreads();
-
-    const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
-    LineLdsSink<MASK, COVERED> sink{g, pl, t_s, t_c, bx * t.bins.tile_w - t.apron,
-                           g.st_r0 + t.bins.row0 + by * t.bins.tile_h - t.apron, t.lw, t.lh};
-    const GlyphRec* rec = records + it.first;
-    // every wave runs the same number of rounds (the walk below is wave-cooperative: shuffles inside)
-    for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
-        const unsigned j = j0 + threadIdx.x;
-        bool valid = j < it.count;
-        LineParams q{};
-        if (valid) {
-            const GlyphRec rc = rec[j];
-            PointGeom pg = point_geom(g, rc.x, rc.y);
-            valid = pg.valid;
-            if (valid) q = line_params(g, gl, pg, rc.v, GlyphChan{rc.c0, rc.c1, rc.c2});
-        }
-        line_walk_wave(q, valid, sink);
-    }
-    __syncthreads();
-
-    for (int i = threadIdx.x; i < cells; i += kThreads) {
-        double s = (MASK & 1) ? t_s[i] : 0.0;
-        unsigned c = (MASK & 2) ? t_c[i] : 0u;
-        if (s == 0.0 && c == 0u) continue;
-        int ly = i / t.lw, lx = i - ly * t.lw;
-        int64_t cell = (int64_t)(sink.y0 + ly - g.st_r0) * g.W + (sink.x0 + lx);
-        if ((MASK & 1) && s != 0.0) atomic_add_f32(pl.sum + cell, (float)s);
-        if ((MASK & 2) && c) atomic_add_f32(pl.wgt + cell, (float)c);
-    }
-}
-
 // ---- Line tiles on 16-byte records (bin16.hpp) -----------------------------------------------------------------
 // Round 2 carried x, y, value and the per-point channels to the tile in 32-byte records and did the end-point
 // arithmetic (an f64 sincos per segment) there.  The scatter pass of the shared front-end has x, y and the channels in
@@ -411,14 +364,6 @@ void launch_gauss(K kernel, pcr_hip_engine* e, const GridDev& gd, const GlyphDev
                        bb.items, bb.n_items, x, y, v);
 }
 
-template <typename K>
-void launch_line(K kernel, pcr_hip_engine* e, const GridDev& gd, const GlyphDev& gl, const GlyphTile& t, const PlanesDev& pl,
-                 const BinBuffers& bb, size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, gl, t, pl, bb.grecords,
-                       bb.items, bb.n_items);
-}
-
 }  // namespace
 
 namespace pcrhip {
@@ -485,7 +430,7 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
             return PCR_HIP_OK;
         }
     }
-    if (gl.type == PCR_HIP_GLYPH_LINE && e->cell_tiles) {
+    if (gl.type == PCR_HIP_GLYPH_LINE) {
         // 16-byte end-point records through the shared front-end (bin16.hpp); bands as below
         const int band16 = band_rows_for(e->gd, S, S, b16::max_bins(e));
         if (band16 <= 0) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: grid cannot be binned");
@@ -505,7 +450,7 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
             t.bins.rows = rows;
             t.bins.bins_y = (rows + S - 1) / S;
             t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
-            t.bins.chunk = b16::chunk_of<LineRecMaker>(e);
+            t.bins.chunk = b16::chunk_of<LineRecMaker>();
             total_bins += t.bins.nbins;
             b16::Buffers bb{};
             rc = b16::bin(e, gd, t.bins, LineRecMaker{gl}, x, y, v, n, item_points, L, &bb);
@@ -554,41 +499,25 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
         t.bins.chunk = t.bins.nbins <= 2048 ? 16384 : 8192;
         total_bins += t.bins.nbins;
         BinBuffers bb{};
-        const bool is_line = gl.type == PCR_HIP_GLYPH_LINE;
-        int rc = bin_points(e, gd, t.bins, x, y, v, n, is_line ? RecordKind::Glyph : RecordKind::Index, &gl, item_points, &bb);
+        int rc = bin_points(e, gd, t.bins, x, y, v, n, RecordKind::Index, &gl, item_points, &bb);
         if (rc) return rc;
-        // the tile kernels re-derive every point's geometry from the engine's grid: the band only selected them
-        if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
-            ScopedKernelTimer tm(e, "k_tile_gauss");
+        // the tile kernel re-derives every point's geometry from the engine's grid: the band only selected them
+        ScopedKernelTimer tm(e, "k_tile_gauss");
 #define PCR_GAUSS(M, FR) launch_gauss(&k_tile_gauss<M, FR>, e, e->gd, gl, t, pl, bb, lds, x, y, v)
 #define PCR_GAUSS_R(M)                                                                          \
-            switch (t.fixed_r) {                                                                \
-                case 1: PCR_GAUSS(M, 1); break;                                                 \
-                case 2: PCR_GAUSS(M, 2); break;                                                 \
-                case 3: PCR_GAUSS(M, 3); break;                                                 \
-                case 4: PCR_GAUSS(M, 4); break;                                                 \
-                case 5: PCR_GAUSS(M, 5); break;                                                 \
-                case 6: PCR_GAUSS(M, 6); break;                                                 \
-                case 7: PCR_GAUSS(M, 7); break;                                                 \
-                default: PCR_GAUSS(M, 0); break;                                                \
-            }
-            if (mask == 1) { PCR_GAUSS_R(1) } else if (mask == 2) { PCR_GAUSS_R(2) } else { PCR_GAUSS_R(3) }
+        switch (t.fixed_r) {                                                                    \
+            case 1: PCR_GAUSS(M, 1); break;                                                     \
+            case 2: PCR_GAUSS(M, 2); break;                                                     \
+            case 3: PCR_GAUSS(M, 3); break;                                                     \
+            case 4: PCR_GAUSS(M, 4); break;                                                     \
+            case 5: PCR_GAUSS(M, 5); break;                                                     \
+            case 6: PCR_GAUSS(M, 6); break;                                                     \
+            case 7: PCR_GAUSS(M, 7); break;                                                     \
+            default: PCR_GAUSS(M, 0); break;                                                    \
+        }
+        if (mask == 1) { PCR_GAUSS_R(1) } else if (mask == 2) { PCR_GAUSS_R(2) } else { PCR_GAUSS_R(3) }
 #undef PCR_GAUSS_R
 #undef PCR_GAUSS
-        } else {
-            ScopedKernelTimer tm(e, "k_tile_line");
-            // per-point half lengths are only bounded by the reference tile: the spill branch stays for them
-            const bool covered = t.apron >= t.need && !gl.half_length;
-#define PCR_LINE(M)                                                                                 \
-            if (covered) launch_line(&k_tile_line<M, true>, e, e->gd, gl, t, pl, bb, lds);         \
-            else launch_line(&k_tile_line<M, false>, e, e->gd, gl, t, pl, bb, lds);
-            switch (mask) {
-                case 1: PCR_LINE(1) break;
-                case 2: PCR_LINE(2) break;
-                default: PCR_LINE(3) break;
-            }
-#undef PCR_LINE
-        }
     }
     PCR_HIP_TRY(hipGetLastError());
     e->stats.path = 1;

@@ -479,7 +479,7 @@ int cells_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Plan
         gd.own_r1 = std::min(ge.own_r1, ge.st_r0 + row0 + rows);
         if (gd.own_r0 >= gd.own_r1) continue;
         BinGeom b = cell_bins(ge, p, row0, rows);
-        b.chunk = chunk_of<GaussCellMaker>(e);
+        b.chunk = chunk_of<GaussCellMaker>();
         total_bins += b.nbins;
         rc = bin(e, gd, b, GaussCellMaker{}, x, y, v, n, item_records, L, &bb);
         if (rc) return rc;

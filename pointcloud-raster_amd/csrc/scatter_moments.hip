@@ -77,7 +77,7 @@ struct MomentMaker {
 // profiles/r02_moments_split.md).  Tiles are 64 x 16 cells so that a tile's ~3 K records fit three workgroups per CU;
 // a crowded tile is folded in rounds of kSortChunk records.  One workgroup per tile, empty tiles included, so that
 // every moment cell is written and the planes need no memset.
-template <int K, unsigned MASK, bool NT>
+template <int K, unsigned MASK>
 __global__ void __launch_bounds__(kMomThreads)
 k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* __restrict__ records,
                const unsigned* __restrict__ bin_start, float* __restrict__ mom_v, float* __restrict__ mom_w,
@@ -196,13 +196,8 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
                 // written once, read by the column pass much later: streamed past the L2
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    if (NT) {
-                        if (MASK & 1) __builtin_nontemporal_store(acc[p].x, mom_v + p * plane_stride + gcell);
-                        if (MASK & 2) __builtin_nontemporal_store(acc[p].y, mom_w + p * plane_stride + gcell);
-                    } else {
-                        if (MASK & 1) mom_v[p * plane_stride + gcell] = acc[p].x;
-                        if (MASK & 2) mom_w[p * plane_stride + gcell] = acc[p].y;
-                    }
+                    if (MASK & 1) __builtin_nontemporal_store(acc[p].x, mom_v + p * plane_stride + gcell);
+                    if (MASK & 2) __builtin_nontemporal_store(acc[p].y, mom_w + p * plane_stride + gcell);
                 }
             } else if (cnt > 0) {
 #pragma unroll
@@ -816,13 +811,8 @@ void fill_taps(std::vector<float>& t, int K, int r, double s2) {
 template <int K, unsigned MASK>
 void launch_moments(pcr_hip_engine* e, const GridDev& gw, const MomPlan& p, const uint4* rec, const unsigned* bin_start,
                     float* mom_v, float* mom_w, int64_t stride) {
-    // PCR_HIP_TUNE_MOM = 9 (experiments): plain instead of non-temporal plane stores
-    if (e->tune_mom == 9)
-        hipLaunchKernelGGL((k_tile_moments<K, MASK, false>), dim3(p.bins.nbins), dim3(kMomThreads), 0, e->stream, gw, p.bins,
-                           p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
-    else
-        hipLaunchKernelGGL((k_tile_moments<K, MASK, true>), dim3(p.bins.nbins), dim3(kMomThreads), 0, e->stream, gw, p.bins,
-                           p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
+    hipLaunchKernelGGL((k_tile_moments<K, MASK>), dim3(p.bins.nbins), dim3(kMomThreads), 0, e->stream, gw, p.bins,
+                       p.inv2sx2, p.inv2sy2, rec, bin_start, mom_v, mom_w, stride);
 }
 
 template <unsigned MASK>
@@ -934,7 +924,7 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         g.st_rows = mb.win_rows;
         MomPlan pb = p;
         plan_bins(pb, g);
-        pb.bins.chunk = b16::chunk_of<MomentMaker>(e);
+        pb.bins.chunk = b16::chunk_of<MomentMaker>();
         if (pb.bins.nbins > max_bins) return fail(PCR_HIP_CUDA_ERROR, "moment path: band larger than planned");
         const BinGeom& b = pb.bins;
         total_bins += b.nbins;

@@ -1,8 +1,9 @@
 """Kernel variants that the default benchmark shapes do not reach, against the CPU oracle:
   * the matrix-core column pass of the moment path (k_conv_col_mfma) on widths that are not a multiple of 4 (scalar staging),
     odd radii (slack rows), radii that need the 14-round and the unrolled-less staging variants;
-  * the measurement knobs of include/pcr_hip.h (PCR_HIP_TUNE_CONV / _MOM / _REC select alternative kernels that must stay
-    correct: A/B runs quote them).
+  * both column-pass kernels of the moment path at radii where the engine would pick the other one (PCR_HIP_TUNE_CONV = 1 / 2:
+    the one switch that is left; round 3 removed the _SCATTER / _B / _REC / _MOM experiment switches and the opt-in one-pass
+    sort together with the kernels behind them).
 Same tolerance as every Gaussian / Line test (rtol 1e-4, exact NaN mask)."""
 import os
 
@@ -78,9 +79,6 @@ def test_matrix_core_column_pass_shapes(A, case, rname):
 KNOBS = [
     dict(PCR_HIP_TUNE_CONV=1),      # vector-ALU column pass at a radius the matrix cores would take
     dict(PCR_HIP_TUNE_CONV=2),      # matrix cores at a radius the vector ALU would take
-    dict(PCR_HIP_TUNE_MOM=2),
-    dict(PCR_HIP_TUNE_MOM=4),
-    dict(PCR_HIP_TUNE_MOM=9),
 ]
 
 
@@ -94,7 +92,9 @@ def test_measurement_knobs_keep_the_moment_path_exact(A, knob, shape):
         gaussian_case(A, shape["G"], shape["sigma"], shape["maxr"], shape["n"], tile=shape.get("tile", (4096, 4096)))
 
 
-def test_rec_scatter_knob_keeps_lines_exact(A):
+def test_line_records_count_and_sum_exact(A):
+    """Line tiles on 16-byte end-point records (bin16.hpp): Count bit-exact, Sum within tolerance, on a grid with several
+    LDS tiles per side and segments that cross them."""
     W, H, n = 700, 500, 60000
     og = O.make_grid((0.0, 0.0, float(W), float(H)))
     rng = np.random.default_rng(4)
@@ -105,23 +105,45 @@ def test_rec_scatter_knob_keeps_lines_exact(A):
     ogl = O.make_glyph(O.GLYPH_LINE, half_length=9.0, max_radius=11.0)
     grid = A.make_grid((0.0, 0.0, float(W), float(H)), dims=(W, H))
     results = {}
-    for knob in (0, 1):
-        with env(PCR_HIP_TUNE_REC=knob):
-            for rname, mask in (("Count", A.PLANE_WGT), ("Sum", A.PLANE_SUM)):
-                run = A.ReductionRun(grid, mask, path=2)
-                try:
-                    run.scatter(x, y, v, glyph=gl, direction=d)
-                    results[(knob, rname)] = run.finalize(RT[rname])
-                    assert run.stats().path == 1
-                finally:
-                    run.close()
+    for rname, mask in (("Count", A.PLANE_WGT), ("Sum", A.PLANE_SUM)):
+        run = A.ReductionRun(grid, mask, path=2)
+        try:
+            run.scatter(x, y, v, glyph=gl, direction=d)
+            results[rname] = run.finalize(RT[rname])
+            assert run.stats().path == 1
+        finally:
+            run.close()
     want = O.run(og, RT["Count"], x, y, v, glyph=ogl, direction=d)
-    for knob in (0, 1):
-        assert np.array_equal(np.nan_to_num(results[(knob, "Count")], nan=-1.0), np.nan_to_num(want, nan=-1.0)), knob
+    assert np.array_equal(np.nan_to_num(results["Count"], nan=-1.0), np.nan_to_num(want, nan=-1.0))
     want_s = O.run(og, RT["Sum"], x, y, v, glyph=ogl, direction=d)
     exact = O.run(og, RT["Sum"], x, y, v, glyph=ogl, direction=d, wide=True).astype(np.float64)
-    for knob in (0, 1):
-        check(results[(knob, "Sum")], want_s, exact, f"line sum knob {knob}", scale=5.0)
+    check(results["Sum"], want_s, exact, "line sum", scale=5.0)
+
+
+def test_line_segments_beyond_the_record_range_take_the_list(A):
+    """A per-point half_length of tens of thousands of cells does not fit a record's int16 end-point offsets: such
+    segments go to the list and are walked by the direct form (clipped to their reference tile as ever).  Count
+    bit-exact against the oracle."""
+    W, H, n = 300, 200, 5000
+    og = O.make_grid((0.0, 0.0, float(W), float(H)), tile=(128, 64))
+    rng = np.random.default_rng(8)
+    x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    v = rng.uniform(1.0, 2.0, n).astype(np.float32)
+    d = rng.uniform(0, np.pi, n).astype(np.float32)
+    hl = rng.uniform(0.5, 6.0, n).astype(np.float32)
+    hl[::97] = 60000.0                                       # far beyond +-32000 cells
+    gl = dict(type=A.GLYPH_LINE, half_length=2.0, max_radius=1e9)
+    ogl = O.make_glyph(O.GLYPH_LINE, half_length=2.0, max_radius=1e9)
+    grid = A.make_grid((0.0, 0.0, float(W), float(H)), dims=(W, H), tile=(128, 64))
+    run = A.ReductionRun(grid, A.PLANE_WGT, path=2)
+    try:
+        run.scatter(x, y, v, glyph=gl, direction=d, half_length=hl)
+        got = run.finalize(RT["Count"])
+        assert run.stats().path == 1
+    finally:
+        run.close()
+    want = O.run(og, RT["Count"], x, y, v, glyph=ogl, direction=d, half_length=hl)
+    assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0))
 
 
 def _large_gaussian_case(seed):
