@@ -108,3 +108,55 @@ def test_row_block_partition():
     blocks = [row_block(r, 4, 40000, align=4096) for r in range(4)]
     assert all(b0 % 4096 == 0 for b0, _ in blocks) and blocks[-1][1] == 40000
     assert row_block(0, 1, 77) == (0, 77)
+
+
+class _FakePipe:
+    """Stands in for the device pipeline: what ShardedPipeline.ingest asks of it before anything is accumulated."""
+
+    def __init__(self, need):
+        self.need = need
+        self.ingested = 0
+
+    def line_reach_rows(self, cloud):
+        return self.need
+
+    def ingest(self, cloud):
+        self.ingested += 1
+
+
+def _reach_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+    from pcr.distributed import ShardedPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        log = []
+        # round 1: only rank 1 holds a long segment -> BOTH ranks must refuse, neither may have accumulated;
+        # round 2: every need fits the halo -> both ingest
+        for needs in ([3, 20], [3, 8]):
+            sp = ShardedPipeline.__new__(ShardedPipeline)
+            sp.world, sp.rank, sp.group, sp.halo = world, rank, dist.group.WORLD, 8
+            sp._line_hl_groups, sp.tiles_local = True, False
+            sp.pipe = _FakePipe(needs[rank])
+            sp._comm = None
+            try:
+                sp.ingest(object())
+                log.append(("ok", sp.pipe.ingested))
+            except RuntimeError as e:
+                log.append(("refused", sp.pipe.ingested, "reaches 20 rows" in str(e)))
+            sp.pipe = None                      # nothing for close() to release
+        dist.barrier()                          # a rank that raised alone would have left the other one here
+        with open(os.path.join(out_dir, f"reach{rank}.txt"), "w") as f:
+            f.write(repr(log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_line_reach_is_agreed_before_anything_is_accumulated(tmp_path):
+    """ShardedPipeline.ingest: the largest Line reach over all ranks decides, so that every rank refuses the round
+    (or none does) -- checked over gloo with a stand-in for the device pipeline."""
+    mp.spawn(_reach_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        log = eval((tmp_path / f"reach{r}.txt").read_text())
+        assert log == [("refused", 0, True), ("ok", 1)], (r, log)

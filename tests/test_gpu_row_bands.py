@@ -103,6 +103,31 @@ def test_glyph_large_grid_paths_match_oracle(A, few_bins, monkeypatch, kind, mod
         np.testing.assert_array_equal(gotc, O.run(og, RT["Count"], x, y, v, glyph=ogl, **ch))
 
 
+@pytest.mark.parametrize("tile", [(4096, 4096), (64, 64)])
+@pytest.mark.parametrize("sigma", [0.3, 0.6, 1.0])
+def test_gauss_cell_tiles_sweep_row_bands(A, few_bins, tile, sigma):
+    """The register-accumulating cell tiles (radius <= 3) under a tiny bin limit: 4 tiles across, one tile row of 20 cell
+    rows per band, 30 bands - every footprint that straddles a band edge is painted by the band that owns its centre."""
+    og = O.make_grid((0.0, 0.0, 200.0, 600.0), tile=tile)
+    rng = np.random.default_rng(int(sigma * 10))
+    n = 60_000
+    x = rng.uniform(-2.0, 202.0, n)
+    y = rng.uniform(-2.0, 602.0, n)
+    v = rng.uniform(1.0, 2.0, n).astype(np.float32)
+    gl = dict(type=A.GLYPH_GAUSSIAN, sigma_x=sigma, sigma_y=sigma, max_radius=3.0)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sigma, sigma_y=sigma, max_radius=3.0)
+    rt = RT["WeightedAverage"]
+    got, st = run_gpu(A, og, rt, x, y, v, glyph=gl)
+    assert st.path == 1 and st.num_bins > 4 * few_bins, "the band sweep was not taken"
+    want = O.run(og, rt, x, y, v, glyph=ogl)
+    exact = O.run(og, rt, x, y, v, glyph=ogl, wide=True).astype(np.float64)
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert (gn != wn).sum() <= 2
+    both = ~gn & ~wn
+    err = np.abs(got[both].astype(np.float64) - exact[both])
+    assert (err <= 1e-4 * np.maximum(1e-3, np.abs(exact[both]))).all()
+
+
 @pytest.mark.parametrize("mode", ["two_level", "bands"])
 def test_point_large_grid_paths_inside_a_row_block_shard(A, few_bins, monkeypatch, mode):
     """Both compose with the owned-row window: a shard owning rows [200, 520) of 700."""
