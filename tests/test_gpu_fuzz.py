@@ -139,7 +139,28 @@ def test_random_case_matches_oracle(A, seed):
         tol = 1e-5 * np.maximum(10.0, mag[fin])
     else:
         tol = 1e-4 * np.maximum(1e-3 * (1.0 if c["rname"] == "Count" else 10.0), mag[fin])
+    if c["kind"].startswith("gauss") and st.path != 2:
+        # The splat paths form a weight as a product of per-axis factors (within 2 ulp of the reference's single expf,
+        # glyph_device.hpp), so a contribution sitting on the reference's `w < 1e-6f` cut-off (glyph_kernels.cu:166) may be
+        # kept where the reference drops it or the other way round -- the same class of difference as the NaN-mask
+        # allowance above.  Where a cell's total weight is itself tiny that one contribution is visible: allow TWO such
+        # contributions per cell (soak seed 11622: one flip, cell weight 2.5e-3, Average off by 3e-3 relative).
+        vmax = float(np.max(np.abs(c["v"][np.isfinite(c["v"])]), initial=0.0))
+        if c["rname"] == "Count":
+            tol = tol + 2e-6
+        elif c["rname"] == "Sum":
+            tol = tol + 2e-6 * vmax
+        else:
+            wsum = O.run(og, RT["Count"], c["x"], c["y"], c["v"], glyph=c["ogl"], wide=True, **c["ch"]).astype(np.float64)
+            tol = tol + 2e-6 * (vmax + np.abs(exact[fin])) / np.maximum(np.nan_to_num(wsum[fin]), 1e-6)
     assert (err <= tol).all(), f"{what}: max err/tol {np.max(err / tol):.3g}"
+
+
+@pytest.mark.parametrize("seed", [11622])
+def test_seeds_the_soak_runs_found(A, seed):
+    """tests/soak_fuzz.py over seeds 10000-40000 (round 3): the one case that failed the comparison as first written
+    (a contribution on the 1e-6 cut-off, see the allowance above)."""
+    test_random_case_matches_oracle(A, seed)
 
 
 def _planes_of(A, og, c, own_rows, halo):
