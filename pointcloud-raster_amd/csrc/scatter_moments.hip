@@ -395,24 +395,30 @@ constexpr int kColStride = 80;
 // in flight in registers behind the sweep of the previous plane.  The first version staged one float per lane with
 // wave-uniform row pointers and validity (as k_conv_col does): ~670 scalar instructions per plane and wave, as much
 // issue time as the MFMAs themselves (profiles/r02_conv_mfma.md).  NI == 0: plain float loop, any width.
-template <int NI>
-__global__ void __launch_bounds__(256)
+// NW waves per workgroup = 16 NW output rows x 64 columns.  Four waves stage 64 + 2r rows for 64 outputs; eight stage
+// 128 + 2r for 128: at r = 48 that is 7 staging loads per wave and plane instead of 11, and a SIMD hosts four sweeping
+// waves (two workgroups of eight) instead of three -- the waits this kernel has are on the CU's one texture-address path,
+// where every 1-KB load instruction takes ~190 cycles to issue in the burst after a barrier
+// (profiles/r03_conv_col_phases.md).
+template <int NI, int NW>
+__global__ void __launch_bounds__(64 * NW)
 k_conv_col_mfma(GridDev g, int K, int r, int yblocks_per_tile, const float* __restrict__ taps_y,
                 const float* __restrict__ mom, int64_t plane_stride, float* __restrict__ u_out) {
-    extern __shared__ float lds_f[];                   // [48 + 4 steps][kColStride] sources | (K + 1) tap tables
+    constexpr int kT = 64 * NW, kRowsWg = 16 * NW, kRowsIt = 4 * NW;      // threads; output rows; rows one staging round covers
+    extern __shared__ float lds_f[];                   // [16 (NW - 1) + 4 steps][kColStride] sources | (K + 1) tap tables
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int x = blockIdx.x * 64 + lane;
     const int trow = blockIdx.y / yblocks_per_tile, yb = blockIdx.y - trow * yblocks_per_tile;
     const int t_lo = max(trow * g.th - g.st_r0, 0), t_hi = min(min((trow + 1) * g.th, g.H) - g.st_r0, g.st_rows);
-    const int Y0 = t_lo + yb * 64;
+    const int Y0 = t_lo + yb * kRowsWg;
     if (Y0 >= t_hi) return;                            // whole workgroup
     const int steps = (16 + 2 * r + 3) >> 2;           // four source rows per step; rows past 16 + 2r meet zero taps
-    const int nsrc = 64 + 2 * r, nalloc = 48 + 4 * steps;   // LDS row s <-> window row Y0 - r + s; the sweep of the last
-                                                            // wave ends at row 48 + 4 steps - 1 (0..3 zero rows of slack)
+    const int nsrc = kRowsWg + 2 * r, nalloc = kRowsWg - 16 + 4 * steps;   // LDS row s <-> window row Y0 - r + s; the sweep of the
+                                                            // last wave ends at row 16 (NW - 1) + 4 steps - 1 (0..3 zero rows of slack)
     const int tap_w = 2 * r + 1 + 2 * kPad;
     float* lds_taps = lds_f + nalloc * kColStride;
-    for (int i = threadIdx.x; i < (K + 1) * tap_w; i += 256) lds_taps[i] = taps_y[i];
+    for (int i = threadIdx.x; i < (K + 1) * tap_w; i += kT) lds_taps[i] = taps_y[i];
     pcr_f4 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] = pcr_f4{0.f, 0.f, 0.f, 0.f};
@@ -420,7 +426,7 @@ k_conv_col_mfma(GridDev g, int K, int r, int yblocks_per_tile, const float* __re
     const bool active = Y0 + wave * 16 < t_hi;
     const int j16 = lane & 15, kg = lane >> 4;
 
-    // staging map: LDS row 16 it + 4 wave + kg, columns 4 j16 .. 4 j16 + 3
+    // staging map: LDS row 4 NW it + 4 wave + kg, columns 4 j16 .. 4 j16 + 3
     const int srow0 = 4 * wave + kg, c4 = 4 * j16;
     const bool cin = blockIdx.x * 64 + c4 < g.W;       // W % 4 == 0: the four columns are inside together
     const int lo_s = t_lo - (Y0 - r), hi_s = min(t_hi - (Y0 - r), nsrc);       // valid LDS rows [lo_s, hi_s)
@@ -430,9 +436,9 @@ k_conv_col_mfma(GridDev g, int K, int r, int yblocks_per_tile, const float* __re
                                          (blockIdx.x * 64 + c4);
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            const int sr = srow0 + 16 * it;
+            const int sr = srow0 + kRowsIt * it;
             const bool ok = cin && sr >= lo_s && sr < hi_s;
-            pre[it] = ok ? *reinterpret_cast<const pcr_f4*>(base + (int64_t)16 * it * g.W) : pcr_f4{0.f, 0.f, 0.f, 0.f};
+            pre[it] = ok ? *reinterpret_cast<const pcr_f4*>(base + (int64_t)kRowsIt * it * g.W) : pcr_f4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // One workgroup walks ALL pairs (k, l), l = 0..K-k, of its 64 x 64 outputs: the load of the next plane is always
@@ -446,21 +452,21 @@ k_conv_col_mfma(GridDev g, int K, int r, int yblocks_per_tile, const float* __re
             float* dst = lds_f + srow0 * kColStride + c4;
 #pragma unroll
             for (int it = 0; it < NI; ++it)
-                if (srow0 + 16 * it < nalloc) *reinterpret_cast<pcr_f4*>(dst + 16 * it * kColStride) = pre[it];
+                if (srow0 + kRowsIt * it < nalloc) *reinterpret_cast<pcr_f4*>(dst + kRowsIt * it * kColStride) = pre[it];
         } else {
             const float* __restrict__ plane = mom + (int64_t)pair * plane_stride;
             const int xc = xin ? x : 0;
-            for (int s0 = wave; s0 < nalloc; s0 += 32) {
+            for (int s0 = wave; s0 < nalloc; s0 += 8 * NW) {
                 float vals[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int sr = s0 + 4 * u, yy = Y0 - r + sr;
+                    const int sr = s0 + NW * u, yy = Y0 - r + sr;
                     const float* __restrict__ rowp = plane + (int64_t)yy * g.W;
                     vals[u] = (sr < nsrc && yy >= t_lo && yy < t_hi) ? rowp[xc] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (s0 + 4 * u < nalloc) lds_f[(s0 + 4 * u) * kColStride + lane] = vals[u];
+                    if (s0 + NW * u < nalloc) lds_f[(s0 + NW * u) * kColStride + lane] = vals[u];
             }
         }
         __syncthreads();
@@ -897,6 +903,15 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
     const int col_rows_per_wave = (64 + 2 * p.r + 4 + 3) / 4;
     const int col_rows_mfma = 48 + 4 * ((16 + 2 * p.r + 3) >> 2);       // three workgroups per CU at r = 48, K = 3
     const size_t col_lds_mfma = ((size_t)col_rows_mfma * kColStride + (size_t)(p.K + 1) * tap_w) * sizeof(float);
+    // eight waves (128 output rows) per workgroup where two such workgroups fit a CU and the reference tile has the rows
+    const int col_rows_mfma8 = col_rows_mfma + 64;
+    const size_t col_lds_mfma8 = ((size_t)col_rows_mfma8 * kColStride + (size_t)(p.K + 1) * tap_w) * sizeof(float);
+    int col_nw = (col_lds_mfma8 <= (size_t)80 * 1024 && std::min(ge.th, ge.H) >= 128) ? 8 : 4;
+    if (const char* t = std::getenv("PCR_HIP_CONV_WAVES")) {            // experiments: force the workgroup shape
+        const int v = std::atoi(t);
+        if (v == 4 || (v == 8 && col_lds_mfma8 <= (size_t)160 * 1024)) col_nw = v;
+    }
+    const int yblocks8 = (std::min(ge.th, ge.H) + 127) / 128;
     // row pass shape: the strip width (1024 / 256 / 64 columns) that wastes the fewest lanes on this tile width
     const int eff_tw = std::min(ge.tw, ge.W);
     int lpr_shift = 6;
@@ -949,6 +964,10 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds_mfma);
             hipLaunchKernelGGL(kernel, dim3(col_grid.x, col_grid.y, 1), dim3(256), col_lds_mfma, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
         };
+        auto launch_col_mfma8 = [&](auto kernel, const float* src) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds_mfma8);
+            hipLaunchKernelGGL(kernel, dim3(col_grid.x, g.tiles_y * yblocks8, 1), dim3(512), col_lds_mfma8, e->stream, g, p.K, p.r, yblocks8, taps_y, src, cells, d_u);
+        };
         auto launch_col = [&](auto kernel, const float* src) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
             hipLaunchKernelGGL(kernel, col_grid, dim3(256), col_lds, e->stream, g, p.K, p.r, yblocks, taps_y, src, cells, d_u);
@@ -968,13 +987,17 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
                 // matrix-core sweep from r = 24 (15 % faster at r = 48, 7 % slower at r = 12 where the pass is HBM-bound
                 // either way); PCR_HIP_TUNE_CONV = 1 / 2 force the vector-ALU / the MFMA sweep (experiments)
                 if (e->tune_conv == 2 || (e->tune_conv != 1 && p.r >= 24)) {
-                    const int ni = (col_rows_mfma + 15) / 16;         // 16-row staging rounds
+                    const int ni = (col_rows_mfma + 15) / 16;         // 16-row staging rounds (four waves)
+                    const int ni8 = (col_rows_mfma8 + 31) / 32;       // 32-row staging rounds (eight waves)
                     const bool vec = g.W % 4 == 0 && cells % 4 == 0 && (reinterpret_cast<uintptr_t>(mom) & 15) == 0;
-                    if (vec && ni <= 6) launch_col_mfma(&k_conv_col_mfma<6>, mom);
-                    else if (vec && ni <= 8) launch_col_mfma(&k_conv_col_mfma<8>, mom);
-                    else if (vec && ni <= 11) launch_col_mfma(&k_conv_col_mfma<11>, mom);
-                    else if (vec && ni <= 14) launch_col_mfma(&k_conv_col_mfma<14>, mom);
-                    else launch_col_mfma(&k_conv_col_mfma<0>, mom);
+                    if (vec && col_nw == 8 && ni8 <= 6) launch_col_mfma8(&k_conv_col_mfma<6, 8>, mom);
+                    else if (vec && col_nw == 8 && ni8 <= 7) launch_col_mfma8(&k_conv_col_mfma<7, 8>, mom);
+                    else if (vec && col_nw == 8 && ni8 <= 8) launch_col_mfma8(&k_conv_col_mfma<8, 8>, mom);
+                    else if (vec && ni <= 6) launch_col_mfma(&k_conv_col_mfma<6, 4>, mom);
+                    else if (vec && ni <= 8) launch_col_mfma(&k_conv_col_mfma<8, 4>, mom);
+                    else if (vec && ni <= 11) launch_col_mfma(&k_conv_col_mfma<11, 4>, mom);
+                    else if (vec && ni <= 14) launch_col_mfma(&k_conv_col_mfma<14, 4>, mom);
+                    else launch_col_mfma(&k_conv_col_mfma<0, 4>, mom);
                 } else if (col_rows_per_wave <= 24) launch_col(&k_conv_col<24>, mom);
                 else if (col_rows_per_wave <= 32) launch_col(&k_conv_col<32>, mom);
                 else if (col_rows_per_wave <= 48) launch_col(&k_conv_col<48>, mom);
