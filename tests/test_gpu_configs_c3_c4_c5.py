@@ -209,3 +209,36 @@ def test_c2_full_size_sum_count_average_vs_oracle_window():
     assert (np.abs(gs[occ].astype(np.float64) - ws[occ]) <= 1e-5 * np.maximum(1.0, np.abs(ws[occ]))).all()
     assert (np.abs(ga[occ].astype(np.float64) - wa[occ]) <= 1e-5 * np.maximum(1.0, np.abs(wa[occ]))).all()
     assert (gs[~occ] == 0.0).all()                                  # Q2: Sum of an empty cell inside a touched tile
+
+
+@pytest.mark.parametrize("sigma,max_r,win", [(1.0, 4.0, 128), (16.0, 64.0, 48)], ids=["sigma1_cell_tiles", "sigma16_moments"])
+def test_bench_gaussian_clouds_full_size_vs_oracle_window(sigma, max_r, win):
+    """The two Gaussian clouds of bench.py's per_glyph legs exactly as the driver times them (50 M uniform points, 4096^2,
+    seed 42; sigma = 1 through the register-accumulating cell tiles, sigma = 16 through moments + the matrix-core column pass):
+    every cell of a window against the oracle run on the points whose footprint can reach it."""
+    G, n = 4096, 50_000_000
+    rng = np.random.default_rng(42)                                 # bench.py make_points(...)
+    x, y = rng.uniform(2, G - 2, n), rng.uniform(2, G - 2, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G))
+    gs = pcr.gaussian_splat_spec("value", default_sigma=sigma, max_radius_cells=max_r)
+    p = pcr.Pipeline.create(config_for(og, [gs], scatter_path=0, gpu_pool_size_bytes=24 * n + (64 << 20)))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    info = p.last_scatter()
+    assert info["points_valid"] == n and info["path"] == ("binned" if sigma == 1.0 else "moments"), info
+    got = bands(p)[0]
+    del p
+    reach = int(np.ceil(min(3.0 * sigma, max_r)))
+    lo = 2010                                                        # straddles tile edges of both forms (58 x 20, 64 x 16)
+    hi = lo + win
+    sel = (x >= lo - reach - 1) & (x < hi + reach + 1) & (y > G - hi - reach - 1) & (y <= G - lo + reach + 1)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sigma, sigma_y=sigma, max_radius=max_r)
+    want = O.run(og, O.WEIGHTED_AVERAGE, x[sel], y[sel], v[sel], glyph=ogl)[lo:hi, lo:hi]
+    exact = O.run(og, O.WEIGHTED_AVERAGE, x[sel], y[sel], v[sel], glyph=ogl, wide=True)[lo:hi, lo:hi].astype(np.float64)
+    g = got[lo:hi, lo:hi]
+    assert np.array_equal(np.isnan(g), np.isnan(want)), "NaN mask differs from the oracle on the window"
+    both = ~np.isnan(want)
+    assert both.sum() == both.size                                   # ~3 points per cell: every cell is reached
+    err = np.abs(g[both].astype(np.float64) - exact[both])
+    assert (err <= 1e-4 * np.maximum(1e-3, np.abs(exact[both]))).all(), f"max rel err {np.max(err / np.abs(exact[both])):.3g}"
