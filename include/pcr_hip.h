@@ -180,10 +180,12 @@ typedef struct pcr_hip_engine pcr_hip_engine;
 /* scratch_bytes = 0: the engine grows its scratch arena on demand (the arena is shared by all engines of a device).
  * Test-only environment knobs, read here: PCR_HIP_DEBUG_MAX_BINS=<n> lowers the number of LDS tiles one binning pass
  * may count (8064) so that the large-grid paths (two-level sort, row bands) are reached on small grids;
- * PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep where the two-level sort would apply.
- * (the passes on 16-byte glyph records count up to 16384 tiles: the knob applies to them as it stands);
- * PCR_HIP_DEBUG_TWO_LEVEL=0 above.  PCR_HIP_TUNE_CONV=1|2 forces the vector-ALU | matrix-core column pass of the moment path
- * whatever the radius (tests reach both kernels on small shapes; results do not change). */
+ * PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep where the two-level sort would apply
+ * (the passes on 16-byte glyph records count up to 16384 tiles: the knob applies to them as it stands).
+ * PCR_HIP_TUNE_CONV=1|2 forces the vector-ALU | matrix-core column pass of the moment path whatever the radius (tests reach
+ * both kernels on small shapes), PCR_HIP_CONV_WAVES=4|8 the workgroup shape of the matrix-core pass, PCR_HIP_CELL_TILE_H=<rows>
+ * the height of the Gaussian cell tiles (read at scatter time): shapes only, results do not change.  PCR_HIP_RCCL=<path> names
+ * the RCCL library pcr_hip_comm_* loads (default: the copy the process already has, else the one beside libamdhip64). */
 int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s);
 int pcr_hip_engine_destroy(pcr_hip_engine* e);
 /* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot
