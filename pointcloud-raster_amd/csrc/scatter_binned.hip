@@ -52,8 +52,11 @@ __device__ __forceinline__ Routed route(const GridDev& g, const BinGeom& b, doub
 // three 512-thread groups per CU keep half as many loads again in flight.
 constexpr int kCountThreads = 512;
 
+// Blocks [0, full_blocks) take b.chunk points each, the blocks after them 4096 points each (the ragged end): the SAME
+// block -> points mapping as k_bin_scatter's, because with nvx = 8 the counts are kept per virtual XCD (blockIdx % 8) and a
+// point must be counted under the virtual XCD that will store its record (see bin_points).  nvx = 1: one count per bin.
 __global__ void __launch_bounds__(kCountThreads)
-k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __restrict__ y,
+k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* __restrict__ x, const double* __restrict__ y,
             uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
             uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
     extern __shared__ unsigned lds_hist[];
@@ -62,7 +65,9 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
     const bool one_tile = g.tiles_x * g.tiles_y == 1;
-    const uint64_t base = (uint64_t)blockIdx.x * b.chunk;
+    const bool tail = blockIdx.x >= full_blocks;
+    const uint64_t base = tail ? (uint64_t)full_blocks * b.chunk + (uint64_t)(blockIdx.x - full_blocks) * 4096 : (uint64_t)blockIdx.x * b.chunk;
+    const int len = tail ? 4096 : b.chunk;
     unsigned my_valid = 0;
     // The routing is done once: pass B reads the 4-byte key written here instead of x, y (16 B).
     auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
@@ -75,14 +80,14 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
         }
         return 0xFFFFFFFFu;
     };
-    const bool full = base + (uint64_t)b.chunk <= n &&
+    const bool full = base + (uint64_t)len <= n &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (full) {
-        // 16-byte loads (two points per lane), four of them in flight per array before any math
+        // 16-byte loads (two points per lane), four of them in flight per array before any math (len is a multiple of 4096)
         const double2* x2 = reinterpret_cast<const double2*>(x + base);
         const double2* y2 = reinterpret_cast<const double2*>(y + base);
         uint2* k2 = reinterpret_cast<uint2*>(keys + base);
-        const int pairs = b.chunk >> 1;
+        const int pairs = len >> 1;
         for (int p0 = threadIdx.x; p0 < pairs; p0 += 4 * kCountThreads) {
             double2 xs[4], ys[4];
 #pragma unroll
@@ -101,7 +106,7 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
             }
         }
     } else {
-        for (int k = threadIdx.x; k < b.chunk; k += kCountThreads) {
+        for (int k = threadIdx.x; k < len; k += kCountThreads) {
             uint64_t i = base + k;
             if (i >= n) break;
             keys[i] = handle(i, x[i], y[i]);
@@ -109,9 +114,10 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
     __syncthreads();
+    unsigned* mine = bin_count + (size_t)(blockIdx.x & (unsigned)(nvx - 1)) * b.nbins;
     for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) {
         unsigned c = lds_hist[i];
-        if (c) atomicAdd(&bin_count[i], c);
+        if (c) atomicAdd(&mine[i], c);
     }
     if (threadIdx.x == 0 && any_valid) {
         atomicAdd(counters, (unsigned long long)any_valid);
@@ -119,27 +125,34 @@ k_bin_count(GridDev g, BinGeom b, const double* __restrict__ x, const double* __
     }
 }
 
-// Points per workgroup of the count pass (a multiple of 4096).  Every block flushes its LDS histogram with up to nbins
-// global atomics, so many bins want long chunks -- but long chunks mean few blocks in flight.  Measured, k_bin_count ms:
+// Points per workgroup of the count pass.  Every block flushes its LDS histogram with up to nbins global atomics, so many
+// bins want long chunks -- but long chunks mean few blocks in flight.  Measured in round 2, k_bin_count ms:
 //   chunk          8192    16384   32768   65536   131072
 //   1376 bins (C2, 50 M points)        0.228           0.267
 //   2816 bins (16384 x 2048, 125 M)  0.672   0.648   0.630   0.647   0.697
 //   5504 bins (16384 x 4096, 250 M)  1.260   1.193   1.154   1.178   1.231
-inline int count_chunk(int nbins) { return nbins <= 2048 ? 16384 : 32768; }
+// The single-level path now counts in the scatter pass's own blocks (28672 points: between the two best columns), because
+// the counts are kept per virtual XCD and both passes must see a point in the same block (bin_points).
 
 // ---- scan: bin starts + work items ------------------------------------------------------------
 // A bin's records are split into items of at most item_records so that one hot bin cannot
 // serialize the launch on one CU.
+// nvx > 1: counts and cursors are laid out [virtual XCD][bin]; a bin's records are [vx 0 | vx 1 | ...], contiguous.
 __global__ void __launch_bounds__(kThreads)
-k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_count,
+k_bin_scan(int nbins, int nvx, unsigned item_records, const unsigned* __restrict__ bin_count,
            unsigned* __restrict__ cursor, BinItem* __restrict__ items, unsigned* __restrict__ n_items) {
     __shared__ unsigned part[kThreads];
     __shared__ unsigned ipart[kThreads];
     const int per = (nbins + kThreads - 1) / kThreads;
     const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
+    auto total = [&](int i) {
+        unsigned c = 0;
+        for (int v = 0; v < nvx; ++v) c += bin_count[(size_t)v * nbins + i];
+        return c;
+    };
     unsigned s = 0, it = 0;
     for (int i = lo; i < hi; ++i) {
-        unsigned c = bin_count[i];
+        unsigned c = total(i);
         s += c;
         it += (c + item_records - 1) / item_records;
     }
@@ -157,8 +170,11 @@ k_bin_scan(int nbins, unsigned item_records, const unsigned* __restrict__ bin_co
     unsigned run = part[threadIdx.x] - s;                       // exclusive prefixes of this thread's span
     unsigned irun = ipart[threadIdx.x] - it;
     for (int i = lo; i < hi; ++i) {
-        unsigned c = bin_count[i];
-        cursor[i] = run;
+        unsigned c = 0;
+        for (int v = 0; v < nvx; ++v) {
+            cursor[(size_t)v * nbins + i] = run + c;
+            c += bin_count[(size_t)v * nbins + i];
+        }
         unsigned pieces = (c + item_records - 1) / item_records;
         for (unsigned p = 0; p < pieces; ++p) {
             unsigned first = run + p * item_records;
@@ -335,9 +351,10 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
 // cloud in 4096-point chunks through the scalar-load body: one launch (a second, tiny launch was ~10 us of latency).
 template <int THREADS, int PER_THREAD, int WINDOW, bool INDEX>
 __global__ void __launch_bounds__(THREADS, 4)          // <= 128 VGPRs
-k_bin_scatter(BinGeom b, unsigned full_blocks, const unsigned* __restrict__ keys, const float* __restrict__ v,
+k_bin_scatter(BinGeom b, unsigned full_blocks, int nvx, const unsigned* __restrict__ keys, const float* __restrict__ v,
               uint64_t n, unsigned* __restrict__ cursor, uint2* __restrict__ records) {
     extern __shared__ unsigned char lds_dyn[];
+    cursor += (size_t)(blockIdx.x & (unsigned)(nvx - 1)) * b.nbins;      // this workgroup's virtual XCD (bin_points)
     if (blockIdx.x < full_blocks) {
         bin_scatter_chunk<THREADS, PER_THREAD, WINDOW, true, INDEX>(lds_dyn, b, (uint64_t)blockIdx.x * (THREADS * PER_THREAD), keys, v, n,
                                                                     cursor, records);
@@ -349,20 +366,28 @@ k_bin_scatter(BinGeom b, unsigned full_blocks, const unsigned* __restrict__ keys
 
 // One launcher for both users (single-level binning and the first level of the two-level sort): 1024 threads x 28 points,
 // 64 KB staging window (the shape profiles/r02_tune_scatter.md settled on).
+constexpr int kScatterChunk = 1024 * 28;
+constexpr int kVirtualXcds = 8;                    // record sub-ranges per bin (bin_points)
+// full 28672-point chunks of the scatter pass (the rest of the cloud goes in 4096-point blocks)
+inline int scatter_full_blocks(const float* v, uint64_t n, bool index) {
+    const bool aligned = index || (reinterpret_cast<uintptr_t>(v) & 15) == 0;     // the keys are 256-B aligned
+    return aligned ? (int)(n / kScatterChunk) : 0;
+}
+
 template <bool INDEX>
-void launch_bin_scatter(pcr_hip_engine* e, const BinGeom& b, const unsigned* d_keys, const float* v, uint64_t n,
+void launch_bin_scatter(pcr_hip_engine* e, const BinGeom& b, int nvx, const unsigned* d_keys, const float* v, uint64_t n,
                         unsigned* d_cursor, uint2* d_rec) {
     constexpr int kT = 1024, kPer = 28, kWindow = 8192;
     const uint64_t chunk = (uint64_t)kT * kPer;
-    const bool aligned = INDEX || (reinterpret_cast<uintptr_t>(v) & 15) == 0;     // d_keys is 256-B aligned
-    const int full_blocks = aligned ? (int)(n / chunk) : 0;
+    static_assert(kT * kPer == kScatterChunk, "chunk");
+    const int full_blocks = scatter_full_blocks(v, n, INDEX);
     const size_t lds = (size_t)kWindow * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
     const uint64_t done = (uint64_t)full_blocks * chunk;
     const unsigned tail_blocks = (unsigned)((n - done + 4095) / 4096);            // the chunk is a multiple of 4096
     ScopedKernelTimer t(e, "k_bin_scatter");
     auto kernel = &k_bin_scatter<kT, kPer, kWindow, INDEX>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)full_blocks + tail_blocks), dim3(kT), lds, e->stream, b, (unsigned)full_blocks,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)full_blocks + tail_blocks), dim3(kT), lds, e->stream, b, (unsigned)full_blocks, nvx,
                        d_keys, v, n, d_cursor, d_rec);
     e->stats_scatter_chunk = (int)chunk;
 }
@@ -638,9 +663,14 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     const int max_items = b.nbins + (int)(n / item_records) + 1;
     const size_t rec_bytes = sizeof(uint2);
 
+    // Counts and cursors per VIRTUAL XCD (blockIdx % 8; workgroups are dealt to the XCDs round-robin): a bin's record range is
+    // split into eight sub-ranges and a (workgroup, bin) run of ~21 records only ever shares its first and last 128-byte line
+    // with runs written through the same L2, where they merge -- shared between XCDs they left as partial lines (504 MB
+    // written for 400 MB of records, profiles/r02_C2_rocprof.md).  Both passes use the same block -> points mapping.
+    constexpr int nvx = kVirtualXcds;
     size_t off = 0;                                             // scratch carve-up
-    const size_t o_count = off;  off += align256((size_t)b.nbins * 4);
-    const size_t o_cursor = off; off += align256((size_t)b.nbins * 4);
+    const size_t o_count = off;  off += align256((size_t)nvx * b.nbins * 4);
+    const size_t o_cursor = off; off += align256((size_t)nvx * b.nbins * 4);
     const size_t o_nitems = off; off += 256;
     const size_t o_items = off;  off += align256((size_t)max_items * sizeof(BinItem));
     const size_t o_rec = off;    off += align256((size_t)n * rec_bytes);
@@ -654,26 +684,27 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     BinItem* d_items = reinterpret_cast<BinItem*>(s + o_items);
     unsigned* d_keys = reinterpret_cast<unsigned*>(s + o_keys);
 
-    PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)b.nbins * 4, e->stream));
+    PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)nvx * b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        // the count pass has its own chunk: every block flushes its histogram with up to nbins global atomics, so windows
-        // with many bins count in 65536-point chunks (16384 x 4096 rows, 5504 bins: see the comment at count_chunk)
+        // the count pass walks the cloud in the scatter pass's blocks (28672 points, then 4096-point blocks for the ragged end)
         BinGeom bc = b;
-        bc.chunk = count_chunk(b.nbins);
-        const int cblocks = (int)((n + bc.chunk - 1) / bc.chunk);
+        bc.chunk = kScatterChunk;
+        const int full_blocks = scatter_full_blocks(v, n, kind == RecordKind::Index);
+        const uint64_t done = (uint64_t)full_blocks * kScatterChunk;
+        const unsigned cblocks = (unsigned)full_blocks + (unsigned)((n - done + 4095) / 4096);
         hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
-                           gd, bc, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+                           gd, bc, (unsigned)full_blocks, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, item_records, d_count,
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, nvx, item_records, d_count,
                            d_cursor, d_items, d_nitems);
     }
     {
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
-        if (kind == RecordKind::Index) launch_bin_scatter<true>(e, b, d_keys, v, n, d_cursor, d_rec);
-        else launch_bin_scatter<false>(e, b, d_keys, v, n, d_cursor, d_rec);
+        if (kind == RecordKind::Index) launch_bin_scatter<true>(e, b, nvx, d_keys, v, n, d_cursor, d_rec);
+        else launch_bin_scatter<false>(e, b, nvx, d_keys, v, n, d_cursor, d_rec);
         out->records = d_rec;
     }
     PCR_HIP_TRY(hipGetLastError());
@@ -699,15 +730,17 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
                          uint64_t n, bool index_records, unsigned item_records, BinBuffers* out) {
     BinGeom l1 = tiles;                                                   // first level: groups of tiles
     l1.nbins = (tiles.nbins + (1 << tiles.sup_shift) - 1) >> tiles.sup_shift;
-    l1.chunk = l1.nbins <= 2048 ? 16384 : 8192;
+    l1.chunk = kScatterChunk;                                             // the count pass walks the scatter pass's blocks (bin_points)
+    constexpr int nvx = kVirtualXcds;                                     // (measured neutral here: the first level's runs are ~170 records long)
     const unsigned sub_records = kSubPer * kThreads;
-    const int blocks = (int)((n + l1.chunk - 1) / l1.chunk);
+    const int full_blocks = scatter_full_blocks(v, n, index_records);
+    const unsigned blocks = (unsigned)full_blocks + (unsigned)((n - (uint64_t)full_blocks * kScatterChunk + 4095) / 4096);
     const int max_items1 = l1.nbins + (int)(n / sub_records) + 1;
     const int max_items2 = tiles.nbins + (int)(n / item_records) + 1;
 
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
-    const size_t o_count1 = carve((size_t)l1.nbins * 4), o_cursor1 = carve((size_t)l1.nbins * 4), o_nitems1 = carve(4);
+    const size_t o_count1 = carve((size_t)nvx * l1.nbins * 4), o_cursor1 = carve((size_t)nvx * l1.nbins * 4), o_nitems1 = carve(4);
     const size_t o_items1 = carve((size_t)max_items1 * sizeof(BinItem));
     const size_t o_count2 = carve((size_t)tiles.nbins * 4), o_cursor2 = carve((size_t)tiles.nbins * 4), o_nitems2 = carve(4);
     const size_t o_items2 = carve((size_t)max_items2 * sizeof(BinItem));
@@ -721,20 +754,20 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     uint2* d_rec1 = reinterpret_cast<uint2*>(s + o_rec1);
     uint2* d_rec2 = reinterpret_cast<uint2*>(s + o_rec2);
 
-    PCR_HIP_TRY(hipMemsetAsync(U(o_count1), 0, (size_t)l1.nbins * 4, e->stream));
+    PCR_HIP_TRY(hipMemsetAsync(U(o_count1), 0, (size_t)nvx * l1.nbins * 4, e->stream));
     PCR_HIP_TRY(hipMemsetAsync(U(o_count2), 0, (size_t)tiles.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
         hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
-                           e->gd, l1, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+                           e->gd, l1, (unsigned)full_blocks, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, l1.nbins, sub_records, U(o_count1),
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, l1.nbins, nvx, sub_records, U(o_count1),
                            U(o_cursor1), d_items1, U(o_nitems1));
     }
-    if (index_records) launch_bin_scatter<true>(e, l1, U(o_keys), v, n, U(o_cursor1), d_rec1);
-    else launch_bin_scatter<false>(e, l1, U(o_keys), v, n, U(o_cursor1), d_rec1);
+    if (index_records) launch_bin_scatter<true>(e, l1, nvx, U(o_keys), v, n, U(o_cursor1), d_rec1);
+    else launch_bin_scatter<false>(e, l1, nvx, U(o_keys), v, n, U(o_cursor1), d_rec1);
     const int tps = 1 << tiles.sup_shift;
     {
         ScopedKernelTimer t(e, "k_sub_count");
@@ -743,7 +776,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, tiles.nbins, item_records, U(o_count2),
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, tiles.nbins, 1, item_records, U(o_count2),
                            U(o_cursor2), d_items2, U(o_nitems2));
     }
     {

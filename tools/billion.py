@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
+bench._imports()                                   # bench imports torch / pcr lazily (its launcher branch must not)
 from bench import pcr, make_specs
 
 G = 16384

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401
 import bench
+bench._imports()                                   # bench imports torch / pcr lazily (its launcher branch must not)
 from bench import pcr, ShardedPipeline, make_points, make_cloud, make_specs
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"

@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import bench
+bench._imports()                                   # bench imports torch / pcr lazily (its launcher branch must not)
 from bench import pcr, make_cloud, make_specs
 
 G, n = 4096, 50_000_000
