@@ -53,6 +53,11 @@ CASES = [
     dict(name="s2_r6", G=(160, 128), sigma=(2.0, 2.0), maxr=8.0, n=6000, tile=(4096, 4096)),              # smallest sigma: order 9
     dict(name="s3_r9_tiles", G=(200, 150), sigma=(3.0, 3.0), maxr=12.0, n=6000, tile=(64, 64)),
     dict(name="s5_halfcell", G=(256, 128), sigma=(3.0, 3.0), maxr=32.0, n=6000, tile=(4096, 4096), cell=(0.5, -0.5)),
+    # the matrix-core column pass at the radii where its workgroup shape changes: r = 57 is the largest the eight-wave form
+    # stages (eight 32-row rounds), r = 60 falls back to four waves; a 200-row reference tile ends inside a 128-row workgroup
+    dict(name="s19_r57", G=(320, 400), sigma=(19.0, 19.0), maxr=57.0, n=3000, tile=(4096, 4096)),
+    dict(name="s20_r60", G=(320, 400), sigma=(20.0, 20.0), maxr=60.0, n=3000, tile=(4096, 4096)),
+    dict(name="s19_r57_tile200", G=(320, 400), sigma=(19.0, 19.0), maxr=57.0, n=3000, tile=(4096, 200)),
 ]
 
 
