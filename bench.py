@@ -60,20 +60,37 @@ def _imports():
     torch, dist, pcr, ShardedPipeline, row_block = _torch, _dist, _pcr, _SP, _rb
 
 
-def self_launch(n):
+def self_launch(n, limit_s=None):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks with torch.distributed.run as a
-    CHILD process (never exec: this process has not touched the GPU and stays that way), let rank 0's JSON line through on
-    the inherited stdout, and return the child's exit code."""
-    import socket
+    CHILD process in its own process group (never exec: this process has not touched the GPU and stays that way), let rank
+    0's JSON line through on the inherited stdout, and return the child's exit code.  The rendezvous is torchrun's own
+    (`--standalone`: it binds its store to a free port itself -- no pick-then-use race on a busy box).  A run that exceeds
+    the wall-clock limit (PCR_BENCH_LAUNCH_TIMEOUT seconds, default 1500) has its whole process group killed and the
+    launcher exits with 124: a hung collective ends the run instead of the driver's patience."""
+    import signal
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    if limit_s is None:
+        limit_s = float(os.environ.get("PCR_BENCH_LAUNCH_TIMEOUT", "1500"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--standalone", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PCR_BENCH_SELF_LAUNCHED="1")
-    return subprocess.run(cmd, env=env).returncode
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)          # its own process group: killable as a whole
+    try:
+        return child.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py: the {n}-rank run exceeded {limit_s:.0f} s; killing its process group\n")
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(child.pid, sig)                                  # exactly the group this process started
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+
 
 HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 
@@ -306,9 +323,18 @@ def time_steps(pipes, cloud, warmup, world, backend, ingests=1):
 
 def measured_copy_gbs():
     """Device-to-device copy bandwidth of THIS box (read + write bytes per second): the practical roof next to the 8 TB/s
-    data-sheet peak (SURVEY section 8d asks for both)."""
+    data-sheet peak (SURVEY section 8d asks for both).  Three figures over the same 1 GiB buffers:
+      float4_kernel / float4_kernel_nt   the library's hand-written float4 copy (pcr_hip_copy_kernel: 16 B per lane and
+                                         access, four in flight per lane; plain and non-temporal) -- the shape
+                                         MI355X_MICROARCH.md quotes 6.29 TB/s for; the better of the two is the yardstick
+      torch                              torch's Tensor.copy_ (the runtime's blit kernel), round 3's denominator."""
+    import ctypes as C
+    from pcr import _cabi as A
+    L = A.lib()
     a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")       # 1 GiB
     b = torch.empty_like(a)
+    a.fill_(1.0)
+    out = {}
     for _ in range(2):
         b.copy_(a)
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -317,9 +343,29 @@ def measured_copy_gbs():
         b.copy_(a)
     t1.record()
     torch.cuda.synchronize()
-    ms = t0.elapsed_time(t1) / 8
+    out["torch"] = 2.0 * (1 << 30) / (t0.elapsed_time(t1) / 8 * 1e-3) / 1e9
+    nbytes = a.numel() * 4
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        A.check(L.pcr_hip_event_create(C.byref(e)))
+    for key, nt in (("float4_kernel", 0), ("float4_kernel_nt", 1)):
+        for _ in range(2):
+            A.check(L.pcr_hip_copy_kernel(b.data_ptr(), a.data_ptr(), nbytes, nt, None))
+        A.check(L.pcr_hip_event_record(ev[0], None))                   # the null stream: the one the copies are launched on
+        for _ in range(8):
+            A.check(L.pcr_hip_copy_kernel(b.data_ptr(), a.data_ptr(), nbytes, nt, None))
+        A.check(L.pcr_hip_event_record(ev[1], None))
+        A.check(L.pcr_hip_stream_synchronize(None))
+        ms = C.c_float()
+        A.check(L.pcr_hip_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+        out[key] = 2.0 * nbytes / (ms.value / 8 * 1e-3) / 1e9
+    for e in ev:
+        L.pcr_hip_event_destroy(e)
+    ok = bool(torch.equal(a[:1 << 20], b[:1 << 20]))
     del a, b
-    return 2.0 * (1 << 30) / (ms * 1e-3) / 1e9
+    if not ok:
+        raise RuntimeError("copy kernel did not copy")
+    return out
 
 
 def roofline_of(kernels, info, n, bpp, workload, traffic_db):
@@ -371,6 +417,12 @@ def main():
                     help="gloo + --same-device rehearses the N > 1 code path on a one-GPU box")
     ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the untimed exchange self-check")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="N > 1: transport of the timed exchange -- torch.distributed (default) or the library's own "
+                         "pcr_hip_comm_* over RCCL (include/pcr_hip.h); with the nccl backend the OTHER one is run once, "
+                         "untimed, and compared bit for bit (native_exchange in the line)")
+    ap.add_argument("--native-check-limit", type=float, default=120.0,
+                    help="seconds the untimed native-vs-torch exchange check may take before the line is printed without it")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -385,10 +437,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("PCR_BENCH_PG_TIMEOUT", "600")))   # a stuck collective ends the run
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         # communicator set-up is not part of any step
         warm = torch.zeros(1, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(warm)
@@ -440,12 +494,13 @@ def main():
         cfg = make_cfg(wl)
         if cfg_edit:
             cfg_edit(cfg)
-        pipes = [ShardedPipeline(cfg, rank, world, device_id=local_rank) for _ in range(warmup + steps)]
+        pipes = [ShardedPipeline(cfg, rank, world, device_id=local_rank, comm=args.comm if world > 1 else "torch")
+                 for _ in range(warmup + steps)]
         elapsed, kernels, warm = time_steps(pipes, the_cloud if the_cloud is not None else cloud, warmup, world, args.backend,
                                             ingests)
         info = pipes[-1].pipe.last_scatter()
         sp = pipes[-1]
-        extra = {"halo_rows": sp.halo, "tiles_local": sp.tiles_local,
+        extra = {"halo_rows": sp.halo, "tiles_local": sp.tiles_local, "comm": sp.comm_kind if world > 1 else None,
                  "collectives_per_step": dict(zip(("p2p_messages", "all_reduces"), sp.collectives_per_step())),
                  "halo_bytes_sent_per_step": sp.halo_bytes_per_step()}
         if world > 1 and not sp.tiles_local:
@@ -474,7 +529,10 @@ def main():
         (1) every generated point is valid on exactly one rank: sum over ranks of points_valid == points_total;
         (2) Gaussian leg: the weight held by ALL ranks' planes (owned rows + halo rows) before the exchange equals the weight
             in the OWNED rows after it -- nothing lost, nothing counted twice, whatever moved over the wire;
-        (3) the touched-tile union is identical on every rank."""
+        (3) the touched-tile union is identical on every rank.
+        Built in stages: the LOCAL part of a stage runs under try/except, then every rank takes part in the stage's
+        collective whatever happened to it, carrying an error flag -- a rank that failed (out of memory creating the extra
+        pipeline, an engine error) makes every rank skip the rest together instead of leaving the others in an all-reduce."""
         cpu = args.backend != "nccl"
 
         def allsum(vals, dtype):
@@ -482,32 +540,79 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return t.cpu().tolist()
 
-        res = {}
-        sp = ShardedPipeline(make_cfg(workload), rank, world, device_id=local_rank)
-        sp.ingest(cloud)
-        sp.pipe.synchronize()
-        valid_total, offered_total = allsum([int(sp.pipe.last_scatter()["points_valid"]), int(n)], torch.int64)
-        sp.finalize()
+        def local(fn):
+            try:
+                return fn(), None
+            except Exception as exc:
+                return None, repr(exc)
+
+        res = {"comm": args.comm}
+
+        def stage_failed(name, err):
+            """Collective: True on every rank when any rank's local part failed."""
+            bad = allsum([1 if err else 0], torch.int64)[0]
+            if bad:
+                res["ok"] = False
+                res["error"] = f"stage {name}: failed on {int(bad)} rank(s)" + (f"; this rank: {err}" if err else "")
+            return bool(bad)
+
+        # ---- stage 1: Point leg, valid points
+        box = {}
+
+        def s1():
+            box["sp"] = ShardedPipeline(make_cfg(workload), rank, world, device_id=local_rank, comm=args.comm)
+            box["sp"].ingest(cloud)
+            box["sp"].pipe.synchronize()
+            return int(box["sp"].pipe.last_scatter()["points_valid"])
+
+        valid, err = local(s1)
+        if stage_failed("point ingest", err):
+            return res
+        valid_total, offered_total = allsum([valid, int(n)], torch.int64)
+        _, err = local(lambda: box["sp"].finalize())              # (its collectives are the exchange under test)
+        if stage_failed("point finalize", err):
+            return res
+        box.clear()
         res["points_valid_all_ranks"] = int(valid_total)
         res["points_total"] = int(offered_total)
         ok = int(valid_total) == int(offered_total)
-        del sp
 
-        spg = ShardedPipeline(make_cfg("C5_gauss1"), rank, world, device_id=local_rank)
-        spg.ingest(cloud)
-        spg.pipe.synchronize()
-        planes = spg._plane_tensors()
-        s0 = spg.pipe.state_row_begin()
-        o0, o1 = spg.own
-        pre = [float(t.double().sum().item()) for t, _ in planes]
-        halo_pre = [float((t.double().sum() - t[o0 - s0:o1 - s0].double().sum()).item()) for t, _ in planes]
-        torch.cuda.synchronize()
-        spg.exchange()
-        spg.pipe.synchronize()
-        torch.cuda.synchronize()
-        post = [float(t[o0 - s0:o1 - s0].double().sum().item()) for t, _ in planes]
+        # ---- stage 2: Gaussian leg, plane sums around the exchange
+        def s2():
+            spg = ShardedPipeline(make_cfg("C5_gauss1"), rank, world, device_id=local_rank, comm=args.comm)
+            box["spg"] = spg
+            spg.ingest(cloud)
+            spg.pipe.synchronize()
+            planes = spg._plane_tensors()
+            s0 = spg.pipe.state_row_begin()
+            o0, o1 = spg.own
+            pre = [float(t.double().sum().item()) for t, _ in planes]
+            halo_pre = [float((t.double().sum() - t[o0 - s0:o1 - s0].double().sum()).item()) for t, _ in planes]
+            torch.cuda.synchronize()
+            return pre, halo_pre
+
+        got, err = local(s2)
+        if stage_failed("gauss ingest", err):
+            return res
+        pre, halo_pre = got
+        spg = box["spg"]
+        _, err = local(lambda: (spg.exchange(), spg.pipe.synchronize(), torch.cuda.synchronize()))
+        if stage_failed("gauss exchange", err):
+            return res
+
+        def s3():
+            planes = spg._plane_tensors()
+            s0 = spg.pipe.state_row_begin()
+            o0, o1 = spg.own
+            post = [float(t[o0 - s0:o1 - s0].double().sum().item()) for t, _ in planes]
+            return post, int(spg._touched.to(torch.int64).sum().item())
+
+        got, err = local(s3)
+        if stage_failed("gauss sums", err):
+            return res
+        post, mine = got
         tot = allsum(pre + post + halo_pre, torch.float64)
-        k = len(planes)
+        k = len(pre)
         pre_t, post_t, halo_t = tot[:k], tot[k:2 * k], tot[2 * k:]
         rel = [abs(a - b) / max(abs(a), 1e-30) for a, b in zip(pre_t, post_t)]
         res["gauss_planes"] = k
@@ -518,14 +623,58 @@ def main():
         ok = ok and all(r <= 2e-6 for r in rel)          # f32 merges of f32 plane cells, summed in f64
         if not spg.tiles_local:
             ok = ok and all(v > 0 for v in halo_t)       # the blocks cut reference tiles: the halo rows DID hold weight
-        touched = spg._touched.to(torch.int64)
-        mine = int(touched.sum().item())
         t_all = allsum([mine], torch.int64)[0]
         res["touched_tiles"] = mine
         ok = ok and t_all == mine * world
-        spg.pipe.finalize()
+        _, err = local(lambda: spg.pipe.finalize())
+        box.clear()
         del spg
+        if stage_failed("gauss finalize", err):
+            return res
         res["ok"] = bool(ok)
+        return res
+
+    def native_exchange_check():
+        """N > 1 over RCCL, untimed, once: the SAME Gaussian round through both transports of the exchange -- the library's
+        own pcr_hip_comm_halo_reduce (ncclSend / ncclRecv to rank +- 1, agreed geometry, merge kernel) and torch.distributed's
+        batch_isend_irecv -- must leave bit-identical owned rows (both merge `mine + neighbour's` per cell).  Runs under the
+        caller's deadline (a hung collective must not cost the line)."""
+        cpu = args.backend != "nccl"
+        res = {}
+        sps = {}
+        err = None
+        try:
+            for kind in ("torch", "native"):
+                sp = ShardedPipeline(make_cfg("C5_gauss1"), rank, world, device_id=local_rank, comm=kind)
+                sp.ingest(cloud)
+                sps[kind] = sp
+            torch.cuda.synchronize()
+        except Exception as exc:
+            err = repr(exc)
+        flag = torch.tensor([1 if err else 0], dtype=torch.int64, device="cpu" if cpu else "cuda")
+        dist.all_reduce(flag)
+        if int(flag.item()):
+            return {"ok": False, "error": f"set-up failed on {int(flag.item())} rank(s)" + (f"; this rank: {err}" if err else "")}
+        for kind in ("torch", "native"):
+            sps[kind].exchange(timed=True)
+            sps[kind].pipe.synchronize()
+            res[f"exchange_ms_{kind}"] = round(sps[kind].exchange_ms, 4)
+        torch.cuda.synchronize()
+        a, b = sps["torch"], sps["native"]
+        s0 = a.pipe.state_row_begin()
+        o0, o1 = a.own
+        same = True
+        for (ta, _), (tb, _) in zip(a._plane_tensors(), b._plane_tensors()):
+            same = same and bool(torch.equal(ta[o0 - s0:o1 - s0].view(torch.int32), tb[o0 - s0:o1 - s0].view(torch.int32)))
+        same = same and bool(torch.equal(a._touched, b._touched))
+        t = torch.tensor([1 if same else 0], dtype=torch.int64, device="cpu" if cpu else "cuda")
+        dist.all_reduce(t)
+        res["ranks_bit_identical"] = int(t.item())
+        res["ok"] = int(t.item()) == world
+        res["halo_bytes_sent_per_step"] = b.halo_bytes_per_step()
+        for sp in sps.values():
+            sp.pipe.finalize()
+            sp.close()
         return res
 
     traffic_db = {}
@@ -567,7 +716,8 @@ def main():
                        # as the process group itself reports them (nccl IS RCCL on ROCm)
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": ({"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend())) if world > 1 else None,
-                       "state_init": "planes identity-filled at Pipeline.create, outside the clock (~30 us)",
+                       "state_init": "inside the clock: planes are allocated at Pipeline.create but left undefined; the first scatter "
+                                     "defines every cell (binned Point path: stored by the tile pass; other paths: k_state_init fill)",
                        **extra},
         }
         if check is not None:
@@ -584,8 +734,11 @@ def main():
                                     "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
             if world == 1 and not args.same_device:
                 try:
-                    copy = measured_copy_gbs()
-                    roof["measured_copy_GBps"] = round(copy, 1)
+                    rates = measured_copy_gbs()
+                    copy = max(rates["float4_kernel"], rates["float4_kernel_nt"])
+                    roof["measured_copy_GBps"] = round(copy, 1)         # hand-written float4 copy kernel (pcr_hip_copy_kernel)
+                    roof["measured_copy_kernel"] = {k: round(v, 1) for k, v in rates.items() if k != "torch"}
+                    roof["torch_copy_GBps"] = round(rates["torch"], 1)   # round 3's denominator, kept for comparison
                     roof["frac_of_measured_copy"] = round(roof["achieved"] / copy, 5)
                     out["step_roofline"]["frac_of_measured_copy"] = round(out["step_roofline"]["achieved"] / copy, 5)
                 except Exception as exc:                                # informational: never cost the headline
@@ -714,6 +867,41 @@ def main():
                 out["speedup_vs_one_gpu"] = round(out["value"] / one["Mpts/s"], 3)
         dist.barrier()
 
+    # ---- N > 1 over RCCL: the transport that was NOT timed runs the same Gaussian round once and must agree bit for bit
+    hard_exit = False
+    if strong and world > 1 and not args.no_selfcheck and (args.backend == "nccl" or args.comm == "native"):
+        import threading
+        lock = threading.Lock()
+        state = {"printed": False}
+
+        def bail():
+            # a collective of the check never returned: the measurements above are complete -- print them and leave
+            with lock:
+                if state["printed"]:
+                    return
+                state["printed"] = True
+                if rank == 0:
+                    out["native_exchange"] = {"ok": False, "error": f"no answer within {args.native_check_limit:.0f} s (a hung "
+                                              "collective); the timed legs above are unaffected"}
+                    print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(args.native_check_limit, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            ne = native_exchange_check()
+        except Exception as exc:
+            ne = {"ok": False, "error": repr(exc)}
+        timer.cancel()
+        with lock:
+            if state["printed"]:
+                os._exit(0)
+            state["printed"] = True                 # from here on the main thread prints
+        hard_exit = not ne.get("ok", False)          # peers may be gone or stuck: do not wait for them in destroy_process_group
+        if rank == 0:
+            out["native_exchange"] = ne
+
     if rank == 0:
         sample = args.cpu_sample
         if sample < 0:
@@ -727,6 +915,9 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
+        if hard_exit:
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -134,6 +134,10 @@ int pcr_hip_host_free(void* h_ptr);
 int pcr_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, pcr_hip_stream s);  /* async when h_src is pinned */
 int pcr_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, pcr_hip_stream s);
 int pcr_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, pcr_hip_stream s);
+/* Device-to-device copy by a hand-written float4 kernel (16-byte aligned pointers and size; nontemporal != 0: loads and
+ * stores that bypass the caches' allocation).  The yardstick bench.py reports as `measured_copy_GBps`: the streaming rate
+ * this box really reaches, next to the 8 TB/s data-sheet peak (no reference counterpart: measurement only). */
+int pcr_hip_copy_kernel(void* d_dst, const void* d_src, size_t bytes, int nontemporal, pcr_hip_stream s);
 int pcr_hip_memset(void* d_ptr, int byte_value, size_t bytes, pcr_hip_stream s);
 
 /* ---- arena.  replaces: pcr::MemoryPool (include/pcr/engine/memory_pool.h:18-50,
@@ -191,10 +195,16 @@ int pcr_hip_engine_destroy(pcr_hip_engine* e);
 /* 0 = auto, 1 = force direct global atomics, 2 = force binned LDS tiles (INVALID_ARGUMENT if the grid cannot
  * be binned), 3 = force the separable moment + convolution path for Gaussians (other glyphs: as auto) */
 int pcr_hip_engine_set_path(pcr_hip_engine* e, int path);
-/* Hint for the NEXT pcr_hip_scatter_point only (cleared by it): every plane passed to it holds its identity value in
- * every cell (just filled by pcr_hip_plane_fill / pcr_hip_state_init, nothing accumulated or loaded since).  The
- * tile-merge pass then stores instead of read-modify-writes (saves one read of the planes).  Wrong hint = wrong
- * results; the reference initialises tile state on first acquire the same way (src/engine/tile_manager.cpp:272-320). */
+/* State of the planes handed to the NEXT pcr_hip_scatter_point / _glyph only (cleared by it).  Wrong hint = wrong results.
+ *   0  they hold earlier contributions: the merge read-modify-writes (the default);
+ *   1  every cell holds its identity value (just filled by pcr_hip_plane_fill / pcr_hip_state_init, nothing accumulated
+ *      or loaded since): the Point tile-merge stores instead of read-modify-writing (saves one read of the planes);
+ *   2  they are UNDEFINED (never filled): the scatter itself leaves every cell of the state window defined -- the binned
+ *      Point path by storing every cell of every LDS tile, identity included (no pass of its own; a bin the scan had to
+ *      split, or a window swept in several bands / two sort levels, falls back to filling first), every other path by
+ *      filling the planes with identity values before it accumulates (timed as `k_state_init`).
+ * The reference initialises tile state inside ingest, on first acquire (src/engine/tile_manager.cpp:272-320,
+ * src/engine/pipeline.cpp:688-691): with 2 this build's state initialisation is inside the ingest as well. */
 int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh);
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
 /* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */
@@ -251,6 +261,11 @@ int pcr_hip_absmax_f32(const float* d_values, uint64_t n, float* h_result, pcr_h
  * supplied by the caller (NULL: allocated and freed inside, which synchronizes the whole device). */
 int pcr_hip_absmax_f32_masked(const float* d_values, const uint8_t* d_mask, uint64_t n, uint32_t* d_scratch_word,
                               float* h_result, pcr_hip_stream s);
+/* max(+v) and max(-v) over the finite entries the mask keeps (each >= 0; d_scratch_2words: 8 bytes of device memory).
+ * The reference caps a Line's y half-extent with std::min(hy, cap), hy = half_length / cell_size_y (glyph_kernels.cu:228-234):
+ * only the sign of half_length that makes hy POSITIVE is capped, so a shard's halo check needs the two sides apart. */
+int pcr_hip_signed_max_f32_masked(const float* d_values, const uint8_t* d_mask, uint64_t n, uint32_t* d_scratch_2words,
+                                  float* h_max_pos, float* h_max_neg, pcr_hip_stream s);
 
 /* ---- multi-device: the exchange step of row-block shards, over RCCL / xGMI.  New work: the reference is single-device
  *      (cuda_device_id, include/pcr/engine/pipeline.h:68); SURVEY section 8b asks for these entry points, 8e fixes their
@@ -274,8 +289,27 @@ int pcr_hip_comm_unique_id(uint8_t* id128);
 int pcr_hip_comm_create(pcr_hip_comm** out, const uint8_t* id128, int rank, int world, int device);
 int pcr_hip_comm_destroy(pcr_hip_comm* c);
 int pcr_hip_comm_rank(const pcr_hip_comm* c, int* rank, int* world);
+/* halo_reduce cannot hang on arguments that disagree between the ranks: every call first ALL-GATHERS what each rank brings
+ * (one pcr_hip_halo_geom, posted whatever this rank's own arguments were; costs one small collective + a stream sync),
+ * every rank judges the gathered records with the same pure function (pcr_hip_comm_halo_plan), and either all of them post
+ * their sends and receives -- a receive sized from what its sender says it holds -- or all of them return
+ * PCR_HIP_INVALID_ARGUMENT with the same message (a block shorter than a neighbour's apron, blocks that are not contiguous,
+ * a rank that owns no rows, different widths / halos / planes, a rank with invalid arguments).  At most 8 planes per call. */
+typedef struct pcr_hip_halo_geom {
+    int32_t width, state_row0, state_rows, own_row0, own_row1, halo, nplanes;
+    int32_t kinds;             /* plane kinds, 4 bits each, plane 0 in the low bits */
+    int32_t valid;             /* 0: this rank's own arguments were unusable -- everyone refuses */
+    int32_t reserved_;
+} pcr_hip_halo_geom;
 int pcr_hip_comm_halo_reduce(pcr_hip_comm* c, const pcr_hip_halo_plane* planes, int nplanes, int width,
                              int state_row0, int state_rows, int own_row0, int own_row1, int halo, pcr_hip_stream s);
+/* The verdict on `world` gathered records, and rank's message sizes in rows (0: no message).  Pure host code: no
+ * communicator, no device -- what the CPU tests drive. */
+int pcr_hip_comm_halo_plan(const pcr_hip_halo_geom* all, int world, int rank, int* send_up_rows, int* send_dn_rows,
+                           int* recv_up_rows, int* recv_dn_rows);
+/* MAX over the ranks of one host integer (collective; synchronizes the stream): what a sharded ingest agrees on before
+ * anything is accumulated, e.g. the Line reach of this round's clouds, so that every rank refuses together. */
+int pcr_hip_comm_agree_max_i32(pcr_hip_comm* c, int32_t* h_inout, pcr_hip_stream s);
 int pcr_hip_comm_allreduce_max_u32(pcr_hip_comm* c, uint32_t* d_words, int count, pcr_hip_stream s);
 int pcr_hip_comm_allreduce_sum_f64(pcr_hip_comm* c, double* d_values, int count, pcr_hip_stream s);
 int pcr_hip_comm_stats(const pcr_hip_comm* c, uint64_t* halo_reduces, uint64_t* bytes_sent);

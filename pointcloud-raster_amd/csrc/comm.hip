@@ -38,6 +38,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -92,6 +93,7 @@ Rccl* rccl() {
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     });
     return &r;
@@ -129,8 +131,34 @@ struct pcr_hip_comm {
     int rank = 0, world = 1, device = 0;
     float* d_recv = nullptr;            // grow-only landing area for the neighbours' rows
     size_t recv_cap = 0;
-    uint64_t halo_reduces = 0, bytes_sent = 0;
+    int32_t* d_agree = nullptr;         // (world + 1) geometry records: [0] = mine, [1 ..] = everyone's (all-gather target)
+    int32_t* h_agree = nullptr;         // page-locked mirror
+    uint64_t halo_reduces = 0, bytes_sent = 0, agreements = 0;
 };
+
+namespace {
+
+constexpr int kGeomInts = (int)(sizeof(pcr_hip_halo_geom) / sizeof(int32_t));
+static_assert(sizeof(pcr_hip_halo_geom) == 10 * sizeof(int32_t), "pcr_hip_halo_geom is ten int32");
+
+// Every rank's record to every rank: H2D of mine, ncclAllGather, D2H of all, stream sync.  The ONLY thing a rank does
+// before it knows what the others brought -- so it is posted unconditionally, whatever this rank's own arguments were.
+int gather_geoms(pcr_hip_comm* c, Rccl* r, const pcr_hip_halo_geom& mine, pcr_hip_halo_geom* all, hipStream_t st) {
+    if (!c->d_agree) {
+        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom)));
+        PCR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom), hipHostMallocDefault));
+    }
+    __builtin_memcpy(c->h_agree, &mine, sizeof mine);
+    PCR_HIP_TRY(hipMemcpyAsync(c->d_agree, c->h_agree, sizeof mine, hipMemcpyHostToDevice, st));
+    PCR_RCCL_TRY(r, r->AllGather(c->d_agree, c->d_agree + kGeomInts, (size_t)kGeomInts, ncclInt32, c->comm, st), "ncclAllGather");
+    PCR_HIP_TRY(hipMemcpyAsync(c->h_agree + kGeomInts, c->d_agree + kGeomInts, (size_t)c->world * sizeof mine, hipMemcpyDeviceToHost, st));
+    PCR_HIP_TRY(hipStreamSynchronize(st));
+    __builtin_memcpy(all, c->h_agree + kGeomInts, (size_t)c->world * sizeof mine);
+    c->agreements++;
+    return PCR_HIP_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -176,6 +204,8 @@ int pcr_hip_comm_destroy(pcr_hip_comm* c) {
     Rccl* r = rccl();
     if (c->comm && r->CommDestroy) (void)r->CommDestroy(c->comm);
     if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->d_agree) (void)hipFree(c->d_agree);
+    if (c->h_agree) (void)hipHostFree(c->h_agree);
     delete c;
     return PCR_HIP_OK;
 }
@@ -187,70 +217,176 @@ int pcr_hip_comm_rank(const pcr_hip_comm* c, int* rank, int* world) {
     return PCR_HIP_OK;
 }
 
+// The judgement every rank passes on the gathered geometries: a pure function of `all`, so that every rank reaches the
+// SAME verdict -- either all post their sends and receives (with sizes that match by construction: a receive is sized
+// from what the sender says it holds), or all return PCR_HIP_INVALID_ARGUMENT and nobody waits for anybody.
+int pcr_hip_comm_halo_plan(const pcr_hip_halo_geom* all, int world, int rank, int* send_up_rows, int* send_dn_rows,
+                           int* recv_up_rows, int* recv_dn_rows) {
+    PCR_REQUIRE(all && world >= 1 && rank >= 0 && rank < world, "comm_halo_plan: null geometries or rank outside [0, world)");
+    PCR_REQUIRE(send_up_rows && send_dn_rows && recv_up_rows && recv_dn_rows, "comm_halo_plan: null result pointer");
+    *send_up_rows = *send_dn_rows = *recv_up_rows = *recv_dn_rows = 0;
+    auto who = [](int r) { return "rank " + std::to_string(r); };
+    for (int r = 0; r < world; ++r) {
+        const pcr_hip_halo_geom& g = all[r];
+        if (!g.valid) return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: " + who(r) + " was called with invalid arguments (null planes, "
+                                  "non-positive width or state window) or could not allocate its landing area; refused on every rank");
+        if (g.width != all[0].width || g.halo != all[0].halo || g.nplanes != all[0].nplanes || g.kinds != all[0].kinds)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: " + who(r) + " brings width / halo / planes " +
+                        std::to_string(g.width) + " / " + std::to_string(g.halo) + " / " + std::to_string(g.nplanes) + " where rank 0 brings " +
+                        std::to_string(all[0].width) + " / " + std::to_string(all[0].halo) + " / " + std::to_string(all[0].nplanes) +
+                        "; refused on every rank");
+        if (!(g.own_row1 > g.own_row0)) return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: " + who(r) + " owns no rows: use fewer ranks");
+        if (!(g.own_row0 >= g.state_row0 && g.own_row1 <= g.state_row0 + g.state_rows))
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: the owned rows of " + who(r) + " must lie inside its state window");
+        if (r > 0 && all[r - 1].own_row1 != g.own_row0)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: the row blocks of " + who(r - 1) + " and " + who(r) + " are not contiguous");
+    }
+    for (int r = 0; r < world; ++r) {
+        const pcr_hip_halo_geom& g = all[r];
+        const int up = g.own_row0 - g.state_row0, dn = g.state_row0 + g.state_rows - g.own_row1;
+        if (up > g.halo || dn > g.halo)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: " + who(r) + " holds " + std::to_string(up > dn ? up : dn) +
+                        " apron rows beside its block, more than the halo of " + std::to_string(g.halo));
+        // the apron rows a rank holds beyond its block go to ONE neighbour: they must all be that neighbour's rows
+        if (r > 0 && up > all[r - 1].own_row1 - all[r - 1].own_row0)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: the row block of " + who(r - 1) + " (" +
+                        std::to_string(all[r - 1].own_row1 - all[r - 1].own_row0) + " rows) is shorter than the " + std::to_string(up) +
+                        " apron rows " + who(r) + " holds above its block: use fewer ranks or a smaller radius");
+        if (r < world - 1 && dn > all[r + 1].own_row1 - all[r + 1].own_row0)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm_halo_reduce: the row block of " + who(r + 1) + " (" +
+                        std::to_string(all[r + 1].own_row1 - all[r + 1].own_row0) + " rows) is shorter than the " + std::to_string(dn) +
+                        " apron rows " + who(r) + " holds below its block: use fewer ranks or a smaller radius");
+    }
+    if (all[0].halo == 0 || all[0].nplanes == 0) return PCR_HIP_OK;          // agreed: nothing to move
+    const pcr_hip_halo_geom& me = all[rank];
+    if (rank > 0) {
+        *send_up_rows = me.own_row0 - me.state_row0;
+        const pcr_hip_halo_geom& nb = all[rank - 1];
+        *recv_up_rows = nb.state_row0 + nb.state_rows - nb.own_row1;           // its bottom apron = my first rows
+    }
+    if (rank < world - 1) {
+        *send_dn_rows = me.state_row0 + me.state_rows - me.own_row1;
+        const pcr_hip_halo_geom& nb = all[rank + 1];
+        *recv_dn_rows = nb.own_row0 - nb.state_row0;                           // its top apron = my last rows
+    }
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_comm_halo_reduce(pcr_hip_comm* c, const pcr_hip_halo_plane* planes, int nplanes, int width,
                              int state_row0, int state_rows, int own_row0, int own_row1, int halo, pcr_hip_stream s) {
     PCR_REQUIRE(c, "comm_halo_reduce: null communicator");
-    PCR_REQUIRE(nplanes >= 0 && (nplanes == 0 || planes), "comm_halo_reduce: null planes");
-    PCR_REQUIRE(width > 0 && state_rows > 0 && own_row0 >= state_row0 && own_row1 > own_row0 &&
-                    own_row1 <= state_row0 + state_rows && halo >= 0,
-                "comm_halo_reduce: the owned rows must lie inside the state window");
-    if (c->world == 1 || halo == 0 || nplanes == 0) return PCR_HIP_OK;
-    // a footprint reaches at most `halo` rows: only rank +- 1 hold rows of mine as long as every block is that tall
-    PCR_REQUIRE(own_row1 - own_row0 >= halo, "comm_halo_reduce: row block shorter than the glyph halo: use fewer ranks or a smaller radius");
-    Rccl* r = rccl();
     hipStream_t st = static_cast<hipStream_t>(s);
-    const int up_n = own_row0 - state_row0;                       // apron rows I hold above my block: they belong to rank - 1
-    const int dn_n = state_row0 + state_rows - own_row1;          // ... below: rank + 1
-    const int own_n = own_row1 - own_row0;
-    const int recv_n = halo < own_n ? halo : own_n;               // a neighbour holds min(halo, my rows) of my rows
-    const bool has_up = c->rank > 0, has_dn = c->rank < c->world - 1;
-    const size_t slot = (size_t)recv_n * width;                   // floats per (plane, neighbour)
-    const size_t need = slot * 2 * (size_t)nplanes;
+    // What this rank brings.  A rank whose own arguments are bad does NOT return yet: it says so in its record, takes
+    // part in the agreement like everybody else, and every rank refuses together (one rank returning alone would leave
+    // its neighbours in ncclRecv for ever).
+    pcr_hip_halo_geom mine{};
+    mine.width = width; mine.state_row0 = state_row0; mine.state_rows = state_rows;
+    mine.own_row0 = own_row0; mine.own_row1 = own_row1; mine.halo = halo; mine.nplanes = nplanes;
+    bool ok_local = nplanes >= 0 && nplanes <= 8 && (nplanes == 0 || planes) && width > 0 && state_rows > 0 && halo >= 0;
+    uint32_t kinds = 0;
+    for (int p = 0; ok_local && p < nplanes; ++p) {
+        ok_local = planes[p].d_plane != nullptr && planes[p].kind != 0 && planes[p].kind < 16;
+        kinds |= (planes[p].kind & 15u) << (4 * p);
+    }
+    mine.kinds = (int32_t)kinds;
+    mine.valid = ok_local ? 1 : 0;
+    if (c->world == 1) {
+        PCR_REQUIRE(ok_local && own_row0 >= state_row0 && own_row1 > own_row0 && own_row1 <= state_row0 + state_rows,
+                    "comm_halo_reduce: the owned rows must lie inside the state window");
+        return PCR_HIP_OK;
+    }
+    Rccl* r = rccl();
     int prev = -1;
     PCR_HIP_TRY(hipGetDevice(&prev));
     if (prev != c->device) PCR_HIP_TRY(hipSetDevice(c->device));
     struct Restore { int prev, dev; ~Restore() { if (prev != dev) (void)hipSetDevice(prev); } } restore{prev, c->device};
-    if (need > c->recv_cap) {
-        PCR_HIP_TRY(hipStreamSynchronize(st));                    // earlier merges may still read the old block
-        if (c->d_recv) (void)hipFree(c->d_recv);
-        c->d_recv = nullptr;
-        c->recv_cap = 0;
-        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_recv), need * sizeof(float)));
-        c->recv_cap = need;
+
+    // The landing area is sized BEFORE the agreement, from this rank's own arguments (an apron is at most `halo` rows: the
+    // plan refuses anything larger), so that an allocation failure is part of this rank's record too.
+    if (ok_local && halo > 0 && nplanes > 0) {
+        const size_t need = 2 * (size_t)halo * (size_t)width * (size_t)nplanes;
+        if (need > c->recv_cap) {
+            bool grown = hipStreamSynchronize(st) == hipSuccess;      // earlier merges may still read the old block
+            if (grown) {
+                if (c->d_recv) (void)hipFree(c->d_recv);
+                c->d_recv = nullptr;
+                c->recv_cap = 0;
+                grown = hipMalloc(reinterpret_cast<void**>(&c->d_recv), need * sizeof(float)) == hipSuccess;
+            }
+            if (grown) c->recv_cap = need;
+            else { (void)hipGetLastError(); mine.valid = 0; }
+        }
     }
+    std::vector<pcr_hip_halo_geom> all((size_t)c->world);
+    int rc = gather_geoms(c, r, mine, all.data(), st);
+    if (rc) return rc;
+    int send_up = 0, send_dn = 0, recv_up = 0, recv_dn = 0;
+    rc = pcr_hip_comm_halo_plan(all.data(), c->world, c->rank, &send_up, &send_dn, &recv_up, &recv_dn);
+    if (rc) return rc;                                            // the same verdict on every rank
+    if (halo == 0 || nplanes == 0) return PCR_HIP_OK;             // (agreed above: the same on every rank)
+
+    const size_t up_slot = (size_t)recv_up * width, dn_slot = (size_t)recv_dn * width;     // floats per plane (<= halo * width each)
+    const int own_n = own_row1 - own_row0, up_n = own_row0 - state_row0;
+    // Everything between GroupStart and GroupEnd is posted even after a failure: a group left open would swallow the
+    // thread's next RCCL call.  The first error is reported after the group is closed.
+    ncclResult_t first = ncclSuccess;
+    const char* where = "";
+    auto note = [&](ncclResult_t res, const char* what) { if (res != ncclSuccess && first == ncclSuccess) { first = res; where = what; } };
     PCR_RCCL_TRY(r, r->GroupStart(), "ncclGroupStart");
     for (int p = 0; p < nplanes; ++p) {
         float* plane = planes[p].d_plane;
-        if (has_up) {
-            if (up_n > 0) {
-                PCR_RCCL_TRY(r, r->Send(plane, (size_t)up_n * width, ncclFloat, c->rank - 1, c->comm, st), "ncclSend");
-                c->bytes_sent += (uint64_t)up_n * width * 4;
-            }
-            PCR_RCCL_TRY(r, r->Recv(c->d_recv + (size_t)(2 * p) * slot, slot, ncclFloat, c->rank - 1, c->comm, st), "ncclRecv");
+        float* land = c->d_recv + (size_t)p * (up_slot + dn_slot);
+        if (send_up > 0) {
+            note(r->Send(plane, (size_t)send_up * width, ncclFloat, c->rank - 1, c->comm, st), "ncclSend");
+            c->bytes_sent += (uint64_t)send_up * width * 4;
         }
-        if (has_dn) {
-            if (dn_n > 0) {
-                PCR_RCCL_TRY(r, r->Send(plane + (size_t)(state_rows - dn_n) * width, (size_t)dn_n * width, ncclFloat,
-                                        c->rank + 1, c->comm, st), "ncclSend");
-                c->bytes_sent += (uint64_t)dn_n * width * 4;
-            }
-            PCR_RCCL_TRY(r, r->Recv(c->d_recv + (size_t)(2 * p + 1) * slot, slot, ncclFloat, c->rank + 1, c->comm, st), "ncclRecv");
+        if (recv_up > 0) note(r->Recv(land, up_slot, ncclFloat, c->rank - 1, c->comm, st), "ncclRecv");
+        if (send_dn > 0) {
+            note(r->Send(plane + (size_t)(state_rows - send_dn) * width, (size_t)send_dn * width, ncclFloat, c->rank + 1, c->comm, st), "ncclSend");
+            c->bytes_sent += (uint64_t)send_dn * width * 4;
         }
+        if (recv_dn > 0) note(r->Recv(land + up_slot, dn_slot, ncclFloat, c->rank + 1, c->comm, st), "ncclRecv");
     }
-    PCR_RCCL_TRY(r, r->GroupEnd(), "ncclGroupEnd");
+    note(r->GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess) return rccl_fail(r, first, where);
     // what rank - 1 sent is its bottom apron = my first rows; what rank + 1 sent is its top apron = my last rows
-    const int blocks = (int)((slot + 255) / 256 < 2048 ? (slot + 255) / 256 : 2048);
+    auto grid_of = [](size_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); };
     for (int p = 0; p < nplanes; ++p) {
         float* plane = planes[p].d_plane;
-        if (has_up)
-            hipLaunchKernelGGL(k_halo_merge, dim3(blocks), dim3(256), 0, st, planes[p].kind,
-                               plane + (size_t)up_n * width, c->d_recv + (size_t)(2 * p) * slot, (int64_t)slot);
-        if (has_dn)
-            hipLaunchKernelGGL(k_halo_merge, dim3(blocks), dim3(256), 0, st, planes[p].kind,
-                               plane + (size_t)(up_n + own_n - recv_n) * width, c->d_recv + (size_t)(2 * p + 1) * slot, (int64_t)slot);
+        const float* land = c->d_recv + (size_t)p * (up_slot + dn_slot);
+        if (recv_up > 0)
+            hipLaunchKernelGGL(k_halo_merge, dim3(grid_of(up_slot)), dim3(256), 0, st, planes[p].kind,
+                               plane + (size_t)up_n * width, land, (int64_t)up_slot);
+        if (recv_dn > 0)
+            hipLaunchKernelGGL(k_halo_merge, dim3(grid_of(dn_slot)), dim3(256), 0, st, planes[p].kind,
+                               plane + (size_t)(up_n + own_n - recv_dn) * width, land + up_slot, (int64_t)dn_slot);
     }
     PCR_HIP_TRY(hipGetLastError());
     c->halo_reduces++;
+    return PCR_HIP_OK;
+}
+
+// MAX over the ranks of one host integer (H2D, ncclAllReduce, D2H, stream sync): what a sharded ingest agrees on before
+// anything is accumulated -- e.g. the Line reach of this round's clouds -- so that every rank refuses together.
+int pcr_hip_comm_agree_max_i32(pcr_hip_comm* c, int32_t* h_inout, pcr_hip_stream s) {
+    PCR_REQUIRE(c && h_inout, "comm_agree_max_i32: null argument");
+    if (c->world == 1) return PCR_HIP_OK;
+    Rccl* r = rccl();
+    hipStream_t st = static_cast<hipStream_t>(s);
+    int prev = -1;
+    PCR_HIP_TRY(hipGetDevice(&prev));
+    if (prev != c->device) PCR_HIP_TRY(hipSetDevice(c->device));
+    struct Restore { int prev, dev; ~Restore() { if (prev != dev) (void)hipSetDevice(prev); } } restore{prev, c->device};
+    if (!c->d_agree) {
+        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom)));
+        PCR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom), hipHostMallocDefault));
+    }
+    c->h_agree[0] = *h_inout;
+    PCR_HIP_TRY(hipMemcpyAsync(c->d_agree, c->h_agree, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    PCR_RCCL_TRY(r, r->AllReduce(c->d_agree, c->d_agree, 1, ncclInt32, ncclMax, c->comm, st), "ncclAllReduce");
+    PCR_HIP_TRY(hipMemcpyAsync(c->h_agree, c->d_agree, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PCR_HIP_TRY(hipStreamSynchronize(st));
+    *h_inout = c->h_agree[0];
     return PCR_HIP_OK;
 }
 

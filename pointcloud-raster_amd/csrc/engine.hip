@@ -165,6 +165,23 @@ int begin_scatter(pcr_hip_engine* e, uint64_t n) {
 
 }  // namespace
 
+namespace pcrhip {
+
+// State initialisation inside the scatter (the reference initialises tile state inside ingest too, pipeline.cpp:688-691):
+// only the paths that cannot define every cell themselves pay for it.
+int fill_identity(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl) {
+    ScopedKernelTimer t(e, "k_state_init");
+    const int64_t cells = (int64_t)e->gd.st_rows * e->gd.W;
+    int rc = PCR_HIP_OK;
+    if ((mask & PCR_HIP_PLANE_SUM) && (rc = pcr_hip_plane_fill(pl.sum, 0.0f, cells, e->stream)) != PCR_HIP_OK) return rc;
+    if ((mask & PCR_HIP_PLANE_WGT) && (rc = pcr_hip_plane_fill(pl.wgt, 0.0f, cells, e->stream)) != PCR_HIP_OK) return rc;
+    if ((mask & PCR_HIP_PLANE_MAX) && (rc = pcr_hip_plane_fill(pl.mx, -FLT_MAX, cells, e->stream)) != PCR_HIP_OK) return rc;
+    if ((mask & PCR_HIP_PLANE_MIN) && (rc = pcr_hip_plane_fill(pl.mn, FLT_MAX, cells, e->stream)) != PCR_HIP_OK) return rc;
+    return rc;
+}
+
+}  // namespace pcrhip
+
 extern "C" {
 
 int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t scratch_bytes, pcr_hip_stream s) {
@@ -243,7 +260,8 @@ int pcr_hip_engine_set_path(pcr_hip_engine* e, int path) {
 
 int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh) {
     PCR_REQUIRE(e, "engine_planes_fresh: null engine");
-    e->planes_fresh = fresh != 0;
+    PCR_REQUIRE(fresh >= 0 && fresh <= 2, "engine_planes_fresh: 0 (accumulate), 1 (identity-filled) or 2 (undefined) expected");
+    e->planes_fresh = fresh;
     return PCR_HIP_OK;
 }
 
@@ -332,11 +350,12 @@ int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_point: binned path forced but not applicable to this grid");
     if (e->forced_path == 1 || !can_bin) {
-        e->planes_fresh = false;
+        if (e->planes_fresh == 2 && (rc = fill_identity(e, plane_mask, pl)) != PCR_HIP_OK) return rc;
+        e->planes_fresh = 0;
         return direct_point(e, plane_mask, pl, d_x, d_y, d_value, n);
     }
     rc = binned_point(e, plane_mask, pl, d_x, d_y, d_value, n);
-    e->planes_fresh = false;                              // the hint covers one scatter
+    e->planes_fresh = 0;                                  // the hint covers one scatter
     release_scratch(e);
     return rc;
 }
@@ -372,7 +391,9 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     gl.sigma_y = glyph->d_sigma_y;
     gl.rotation = glyph->d_rotation;
     DeviceGuard dev(e->device);
-    e->planes_fresh = false;                              // glyph merges always accumulate
+    // glyph merges always accumulate (atomics, overlapping aprons): undefined planes are given their identity values first
+    if (e->planes_fresh == 2 && (rc = fill_identity(e, plane_mask, pl)) != PCR_HIP_OK) return rc;
+    e->planes_fresh = 0;
     rc = begin_scatter(e, n);
     if (rc) return rc;
     if (e->forced_path == 3 || e->forced_path == 0) {

@@ -25,7 +25,9 @@ struct pcr_hip_engine {
                                                // path (tests reach both kernels on small shapes)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
     pcr_hip_scatter_stats stats{};
-    bool planes_fresh = false;                 // pcr_hip_engine_planes_fresh: the NEXT scatter's planes hold identity values
+    int planes_fresh = 0;                      // pcr_hip_engine_planes_fresh, for the NEXT scatter: 0 its planes hold earlier
+                                               // contributions, 1 they hold identity values, 2 they are UNDEFINED (the
+                                               // scatter defines every cell of the state window, see engine.hip)
 
     // optional per-kernel event timing
     bool profiling = false;
@@ -82,7 +84,7 @@ struct BinItem {                        // one workgroup's share of a bin's reco
 struct BinBuffers {                     // device pointers into the engine's scratch arena
     const uint2* records;               // Value / Index records, grouped by bin; .x = local cell
     const BinItem* items;
-    const unsigned* n_items;
+    const unsigned* n_items;            // [0] = items, [1] = 1 when some bin was split into several items
     int max_items;
 };
 constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 8 B per bin; beyond this the runs a
@@ -106,8 +108,11 @@ inline int band_rows_for(const GridDev& g, int tile_w, int tile_h, int max_bins)
 //   Index  8 B {local cell, point index}   Gaussian tiles with per-point sigma / rotation channels or r > 3 (the others, and
 //                                          Lines, bin 16-byte value records: bin16.hpp)
 enum class RecordKind { Value, Index };
+// every_bin: an item (possibly of zero records) for EVERY bin, so that the tile pass visits every cell of the band.
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
-               uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out);
+               uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out, bool every_bin = false);
+// Identity values (0, 0, -FLT_MAX, +FLT_MAX) into the planes of `mask` over the engine's state window (engine.hip).
+int fill_identity(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl);
 
 // Two-level counting sort (groups of 2^shift tiles, then tiles) for windows with more tiles than one pass counts;
 // 8-byte Value or Index records.  two_level_shift: 0 when not applicable (disabled, or more than kMaxTiles tiles).

@@ -110,9 +110,49 @@ k_absmax(const float* __restrict__ v, const unsigned char* __restrict__ mask, ui
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
 }
 
+// max over the finite entries of +v and of -v (each >= 0), one word each
+__global__ void __launch_bounds__(kThreads)
+k_signed_max(const float* __restrict__ v, const unsigned char* __restrict__ mask, uint64_t n, unsigned* __restrict__ out_bits) {
+    float mp = 0.f, mn = 0.f;
+    const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float a = v[i];
+        if (fabsf(a) <= FLT_MAX && (!mask || mask[i])) { mp = fmaxf(mp, a); mn = fmaxf(mn, -a); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mp = fmaxf(mp, __shfl_xor(mp, off, 64));
+        mn = fmaxf(mn, __shfl_xor(mn, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mp > 0.f) atomicMax(out_bits, __float_as_uint(mp));
+        if (mn > 0.f) atomicMax(out_bits + 1, __float_as_uint(mn));
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pcr_hip_signed_max_f32_masked(const float* d_values, const uint8_t* d_mask, uint64_t n, uint32_t* d_scratch_2words,
+                                  float* h_max_pos, float* h_max_neg, pcr_hip_stream s) {
+    PCR_REQUIRE(h_max_pos && h_max_neg, "signed_max_f32: null result pointer");
+    *h_max_pos = *h_max_neg = 0.f;
+    if (n == 0) return PCR_HIP_OK;
+    PCR_REQUIRE(d_values && d_scratch_2words, "signed_max_f32: null array or scratch words");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    PCR_HIP_TRY(hipMemsetAsync(d_scratch_2words, 0, 2 * sizeof(unsigned), st));
+    const uint64_t want = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_signed_max, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(kThreads), 0, st, d_values, d_mask, n, d_scratch_2words);
+    PCR_HIP_TRY(hipGetLastError());
+    unsigned bits[2] = {0u, 0u};
+    PCR_HIP_TRY(hipMemcpyAsync(bits, d_scratch_2words, sizeof bits, hipMemcpyDeviceToHost, st));
+    PCR_HIP_TRY(hipStreamSynchronize(st));
+    static_assert(sizeof(float) == sizeof(unsigned), "float bits");
+    __builtin_memcpy(h_max_pos, &bits[0], sizeof(float));
+    __builtin_memcpy(h_max_neg, &bits[1], sizeof(float));
+    return PCR_HIP_OK;
+}
 
 int pcr_hip_absmax_f32(const float* d_values, uint64_t n, float* h_result, pcr_hip_stream s) {
     return pcr_hip_absmax_f32_masked(d_values, nullptr, n, nullptr, h_result, s);

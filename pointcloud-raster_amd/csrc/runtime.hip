@@ -177,6 +177,53 @@ int pcr_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, pcr_hip_str
     return copy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, s);
 }
 
+}  // extern "C"
+
+// ---- the streaming-copy yardstick ------------------------------------------------------------------------------
+// A hand-written float4 copy (16 bytes per lane and access, four independent accesses in flight per lane): the shape
+// /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for.  bench.py reports it as `measured_copy_GBps`, the practical
+// roof of THIS box, next to torch's copy_ (the runtime's blit kernel) and the 8 TB/s data-sheet peak.
+namespace {
+typedef float pcr_f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256)
+k_copy_f4(pcr_f4v* __restrict__ dst, const pcr_f4v* __restrict__ src, size_t n4) {
+    // a workgroup owns 4 x 256 consecutive float4 (16 KB); lane t reads t, t + 256, t + 512, t + 768: every wave
+    // instruction is one contiguous 1-KB request
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    pcr_f4v v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n4) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n4) { if (NT) __builtin_nontemporal_store(v[u], dst + i); else dst[i] = v[u]; }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int pcr_hip_copy_kernel(void* d_dst, const void* d_src, size_t bytes, int nontemporal, pcr_hip_stream s) {
+    if (bytes == 0) return PCR_HIP_OK;
+    PCR_REQUIRE(d_dst && d_src, "copy_kernel: null pointer");
+    PCR_REQUIRE(((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src) | bytes) & 15) == 0,
+                "copy_kernel: pointers and size must be multiples of 16 bytes");
+    const size_t n4 = bytes / 16;
+    const size_t blocks = (n4 + 1023) / 1024;
+    PCR_REQUIRE(blocks <= 0x7FFFFFFFull, "copy_kernel: more than 2^31 workgroups");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    if (nontemporal)
+        hipLaunchKernelGGL(k_copy_f4<true>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<pcr_f4v*>(d_dst), static_cast<const pcr_f4v*>(d_src), n4);
+    else
+        hipLaunchKernelGGL(k_copy_f4<false>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<pcr_f4v*>(d_dst), static_cast<const pcr_f4v*>(d_src), n4);
+    PCR_HIP_TRY(hipGetLastError());
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_memset(void* d_ptr, int byte_value, size_t bytes, pcr_hip_stream s) {
     if (bytes == 0) return PCR_HIP_OK;
     PCR_REQUIRE(d_ptr, "memset: null pointer");

@@ -138,9 +138,11 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
 // A bin's records are split into items of at most item_records so that one hot bin cannot
 // serialize the launch on one CU.
 // nvx > 1: counts and cursors are laid out [virtual XCD][bin]; a bin's records are [vx 0 | vx 1 | ...], contiguous.
+// every_bin: a bin without records still gets one (empty) item, so that the tile pass visits every cell (state
+// initialisation inside the scatter).  n_items[1] = 1 when some bin was split into several items.
 __global__ void __launch_bounds__(kThreads)
 k_bin_scan(int nbins, int nvx, unsigned item_records, const unsigned* __restrict__ bin_count,
-           unsigned* __restrict__ cursor, BinItem* __restrict__ items, unsigned* __restrict__ n_items) {
+           unsigned* __restrict__ cursor, BinItem* __restrict__ items, unsigned* __restrict__ n_items, int every_bin) {
     __shared__ unsigned part[kThreads];
     __shared__ unsigned ipart[kThreads];
     const int per = (nbins + kThreads - 1) / kThreads;
@@ -151,11 +153,15 @@ k_bin_scan(int nbins, int nvx, unsigned item_records, const unsigned* __restrict
         return c;
     };
     unsigned s = 0, it = 0;
+    int split = 0;
     for (int i = lo; i < hi; ++i) {
         unsigned c = total(i);
         s += c;
-        it += (c + item_records - 1) / item_records;
+        const unsigned pieces = (c + item_records - 1) / item_records;
+        it += (every_bin && pieces == 0) ? 1u : pieces;
+        split |= pieces > 1;
     }
+    split = __syncthreads_or(split);
     part[threadIdx.x] = s;
     ipart[threadIdx.x] = it;
     __syncthreads();
@@ -181,10 +187,11 @@ k_bin_scan(int nbins, int nvx, unsigned item_records, const unsigned* __restrict
             unsigned cnt = min(item_records, c - p * item_records);
             items[irun + p] = BinItem{(unsigned)i, first, cnt, pieces > 1 ? 1u : 0u};
         }
+        if (every_bin && pieces == 0) { items[irun] = BinItem{(unsigned)i, run, 0u, 0u}; pieces = 1; }
         run += c;
         irun += pieces;
     }
-    if (threadIdx.x == kThreads - 1) *n_items = ipart[threadIdx.x];
+    if (threadIdx.x == kThreads - 1) { n_items[0] = ipart[threadIdx.x]; n_items[1] = split ? 1u : 0u; }
 }
 
 // ---- pass B: scatter records, staged through LDS so that every bin's run is written contiguously
@@ -521,6 +528,11 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
              const BinItem* __restrict__ items, const unsigned* __restrict__ n_items, int fresh) {
     extern __shared__ double lds_tile[];
     if (blockIdx.x >= *n_items) return;
+    // fresh: 0 the planes hold earlier contributions (read-modify-write); 1 they hold identity values (the merge stores where
+    // the tile has something); 2 they are UNDEFINED and this launch has an item for every bin: every cell is stored, the
+    // identity included -- unless the scan had to split a bin (n_items[1]), in which case k_fill_if has filled the planes
+    // just before this launch and the merge proceeds as for 1 (a split bin's items merge with atomics).
+    const bool full = fresh == 2 && n_items[1] == 0u;
     const BinItem it = items[blockIdx.x];
     const int cells = b.tile_w * b.tile_h;                     // multiple of 1024
     double* t_sum = lds_tile;
@@ -614,6 +626,7 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
             // the Sum / Count planes leave with non-temporal stores: nothing reads them before the finalize pass, and
             // streaming 134 MB through the L2 only evicts the records still to be folded (C2 step -1.2 %)
             typedef float f4v __attribute__((ext_vector_type(4)));
+            if (full) n1 = n2 = n4 = n8 = true;
             if ((MASK & 1) && n1) { g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
                 __builtin_nontemporal_store(f4v{g1.x, g1.y, g1.z, g1.w}, reinterpret_cast<f4v*>(pl.sum + cell)); }
             if ((MASK & 2) && n2) { g2.x += a2.x; g2.y += a2.y; g2.z += a2.z; g2.w += a2.w;
@@ -628,7 +641,12 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
         if (lx >= w) continue;
         int64_t cell = (int64_t)(r0 + ly) * g.W + (c0 + lx);
         int li = ly * b.tile_w + lx;
-        if (!it.shared) {
+        if (full) {                                    // (an item per bin, none of them shared)
+            if (MASK & 1) pl.sum[cell] = (float)t_sum[li];
+            if (MASK & 2) pl.wgt[cell] = (float)t_wgt[li];
+            if (MASK & 4) pl.mx[cell] = t_max[li];
+            if (MASK & 8) pl.mn[cell] = t_min[li];
+        } else if (!it.shared) {
             if (MASK & 1) { double a = t_sum[li]; if (a != 0.0) pl.sum[cell] += (float)a; }
             if (MASK & 2) { unsigned a = t_wgt[li]; if (a) pl.wgt[cell] += (float)a; }
             if (MASK & 4) { float a = t_max[li]; if (a != -FLT_MAX) pl.mx[cell] = fmaxf(pl.mx[cell], a); }
@@ -642,6 +660,22 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
     }
 }
 
+// Undefined planes, and the scan found a bin it had to split (n_items[1]): such a bin's items merge with atomics, which need
+// defined cells -- the planes get their identity values after all.  A no-op launch otherwise (the usual case).
+__global__ void __launch_bounds__(256)
+k_fill_if(const unsigned* __restrict__ n_items, PlanesDev pl, unsigned mask, int64_t cells4) {
+    if (n_items[1] == 0u) return;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f), lo = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX),
+                 hi = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells4; i += stride) {
+        if (mask & 1) reinterpret_cast<float4*>(pl.sum)[i] = zero;
+        if (mask & 2) reinterpret_cast<float4*>(pl.wgt)[i] = zero;
+        if (mask & 4) reinterpret_cast<float4*>(pl.mx)[i] = lo;
+        if (mask & 8) reinterpret_cast<float4*>(pl.mn)[i] = hi;
+    }
+}
+
 template <unsigned MASK>
 void launch_accum(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const PlanesDev& pl, const BinBuffers& bb) {
     size_t lds = (size_t)b.tile_w * b.tile_h * tile_cell_bytes(MASK);
@@ -649,7 +683,7 @@ void launch_accum(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // fresh: only when every bin is owned by one workgroup of this launch can a store replace the read-modify-write
     hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, b, pl,
-                       bb.records, bb.items, bb.n_items, e->planes_fresh ? 1 : 0);
+                       bb.records, bb.items, bb.n_items, e->planes_fresh);
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -659,7 +693,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 namespace pcrhip {
 
 int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const double* x, const double* y, const float* v,
-               uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out) {
+               uint64_t n, RecordKind kind, const GlyphDev* gl, unsigned item_records, BinBuffers* out, bool every_bin) {
     const int max_items = b.nbins + (int)(n / item_records) + 1;
     const size_t rec_bytes = sizeof(uint2);
 
@@ -699,7 +733,7 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     {
         ScopedKernelTimer t(e, "k_bin_scan");
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, b.nbins, nvx, item_records, d_count,
-                           d_cursor, d_items, d_nitems);
+                           d_cursor, d_items, d_nitems, every_bin ? 1 : 0);
     }
     {
         uint2* d_rec = reinterpret_cast<uint2*>(s + o_rec);
@@ -764,7 +798,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     {
         ScopedKernelTimer t(e, "k_bin_scan");
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, l1.nbins, nvx, sub_records, U(o_count1),
-                           U(o_cursor1), d_items1, U(o_nitems1));
+                           U(o_cursor1), d_items1, U(o_nitems1), 0);
     }
     if (index_records) launch_bin_scatter<true>(e, l1, nvx, U(o_keys), v, n, U(o_cursor1), d_rec1);
     else launch_bin_scatter<false>(e, l1, nvx, U(o_keys), v, n, U(o_cursor1), d_rec1);
@@ -777,7 +811,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     {
         ScopedKernelTimer t(e, "k_bin_scan");
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, tiles.nbins, 1, item_records, U(o_count2),
-                           U(o_cursor2), d_items2, U(o_nitems2));
+                           U(o_cursor2), d_items2, U(o_nitems2), 0);
     }
     {
         ScopedKernelTimer t(e, "k_sub_scatter");
@@ -823,6 +857,19 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     int total_bins = 0;
     BinGeom b = point_bin_geom(e->gd, mask, 0, e->gd.st_rows);
     const int shift = nbands != 1 ? two_level_shift(e, b.nbins) : 0;
+    // Undefined planes (pcr_hip_engine_planes_fresh(e, 2)): one band of bins covers the whole state window, so the tile
+    // pass can define every cell itself -- an item for every bin, every cell stored -- and the state initialisation costs
+    // no pass of its own.  Needs whole float4 groups per plane row (the merge's vector form is per row, the scalar form
+    // covers the rest); anything else (two sort levels, several bands) fills the planes first.
+    const int64_t cells = (int64_t)e->gd.st_rows * e->gd.W;
+    const bool define_all = e->planes_fresh == 2 && nbands == 1 && shift == 0 && cells % 4 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(pl.sum) | reinterpret_cast<uintptr_t>(pl.wgt) |
+                              reinterpret_cast<uintptr_t>(pl.mx) | reinterpret_cast<uintptr_t>(pl.mn)) & 15) == 0;
+    if (e->planes_fresh == 2 && !define_all) {
+        int rc = fill_identity(e, mask, pl);
+        if (rc) return rc;
+        e->planes_fresh = 1;
+    }
     if (shift > 0) {                                            // one sweep, two sort levels
         b.sup_shift = shift;
         BinBuffers bb{};
@@ -850,8 +897,10 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
         b = point_bin_geom(e->gd, mask, row0, rows);
         total_bins += b.nbins;
         BinBuffers bb{};
-        int rc = bin_points(e, gd, b, x, y, v, n, RecordKind::Value, nullptr, kPointItemRecords, &bb);
+        int rc = bin_points(e, gd, b, x, y, v, n, RecordKind::Value, nullptr, kPointItemRecords, &bb, define_all);
         if (rc) return rc;
+        if (define_all)
+            hipLaunchKernelGGL(k_fill_if, dim3(2048), dim3(256), 0, e->stream, bb.n_items, pl, mask, cells / 4);
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {
 #define PCR_ACC(M) case M: launch_accum<M>(e, gd, b, pl, bb); break;

@@ -58,6 +58,7 @@ private:
     ::pcr_hip_comm* comm_ = nullptr;
     int rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, halo_ = 0, width_ = 0;
     bool tiles_local_ = false;
+    bool line_hl_groups_ = false;     // a Line group with a per-point half_length channel: ingest agrees on its reach first
 };
 
 }  // namespace pcr

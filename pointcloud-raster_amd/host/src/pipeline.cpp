@@ -81,7 +81,10 @@ struct Pipeline::Impl {
         uint32_t mask = 0;
         detail::Buffer planes[4];
         pcr_hip_planes view{};
-        bool fresh = true;               // planes still hold their identity fill: the first Point merge may store
+        bool fresh = true;               // nothing has been accumulated yet: the first Point merge may store
+        bool defined = false;            // the planes hold values (identity or accumulated).  They are NOT filled at create:
+                                         // the first scatter defines them inside ingest, as the reference initialises its tile
+                                         // state inside ingest (pipeline.cpp:688-691) -- see define_planes()
     };
     struct Output {                      // one ReductionSpec -> one band
         int group = 0;
@@ -198,9 +201,6 @@ struct Pipeline::Impl {
                 if (!(gr.mask & kPlaneBits[p])) continue;
                 s = gr.planes[p].allocate((size_t)std::max<int64_t>(cells, 1) * sizeof(float), MemoryLocation::Device);
                 if (!s.ok()) return s;
-                float ident = p == 2 ? -3.402823466e+38f : p == 3 ? 3.402823466e+38f : 0.0f;
-                s = detail::hip_status(pcr_hip_plane_fill(static_cast<float*>(gr.planes[p].data()), ident, cells, stream));
-                if (!s.ok()) return s;
             }
             gr.view.d_sum = static_cast<float*>(gr.planes[0].data());
             gr.view.d_wgt = static_cast<float*>(gr.planes[1].data());
@@ -209,6 +209,28 @@ struct Pipeline::Impl {
         }
         if (!outputs.empty() && !(s = allocate_result()).ok()) return s;
         return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    }
+
+    // Identity values into a group's planes, for every reader that may come before the group's first scatter (finalize
+    // of an empty pipeline, checkpoints, the halo exchange of a rank without points, state_planes()).
+    Status define_planes(Group& gr) {
+        if (gr.defined) return Status::success();
+        const int64_t cells = (int64_t)hg.state_rows * hg.width;
+        for (int p = 0; p < 4; ++p) {
+            if (!(gr.mask & kPlaneBits[p])) continue;
+            const float ident = p == 2 ? -3.402823466e+38f : p == 3 ? 3.402823466e+38f : 0.0f;
+            Status s = detail::hip_status(pcr_hip_plane_fill(static_cast<float*>(gr.planes[p].data()), ident, cells, stream));
+            if (!s.ok()) return s;
+        }
+        gr.defined = true;
+        return Status::success();
+    }
+    Status define_all_planes() {
+        for (auto& gr : groups) {
+            Status s = define_planes(gr);
+            if (!s.ok()) return s;
+        }
+        return Status::success();
     }
 
     // rows a glyph can reach above/below its centre row (sizes the halo of a row-block shard)
@@ -243,13 +265,17 @@ struct Pipeline::Impl {
             Status a = word.allocate(256, MemoryLocation::Device);
             if (!a.ok()) return a;
         }
-        float amax = 0.f;
-        Status s = detail::hip_status(pcr_hip_absmax_f32_masked(static_cast<const float*>(d_half_length), d_mask, n,
-                                                                static_cast<uint32_t*>(word.data()), &amax, stream));
+        // hy = half_length / cell_size_y goes through std::min(hy, cap) (glyph_kernels.cu:228-234): the sign of half_length
+        // that makes hy positive is capped by max_radius_cells, the other one reaches |half_length / cell_size_y| rows
+        float max_pos = 0.f, max_neg = 0.f;
+        Status s = detail::hip_status(pcr_hip_signed_max_f32_masked(static_cast<const float*>(d_half_length), d_mask, n,
+                                                                    static_cast<uint32_t*>(word.data()), &max_pos, &max_neg, stream));
         if (!s.ok()) return s;
-        double rows = std::ceil((double)amax / std::fabs(cfg.grid.cell_size_y));
-        // std::min(h, cap) caps a POSITIVE hy only (south-up grids, cell_size_y > 0): glyph_kernels.cu:228-234
-        if (cfg.grid.cell_size_y > 0) rows = std::min<double>(rows, std::ceil(std::max(gl.max_radius_cells, 0.0f)));
+        const double acsy = std::fabs(cfg.grid.cell_size_y);
+        const float capped_side = cfg.grid.cell_size_y > 0 ? max_pos : max_neg;
+        const float free_side = cfg.grid.cell_size_y > 0 ? max_neg : max_pos;
+        double rows = std::max(std::ceil((double)free_side / acsy),
+                               std::min(std::ceil((double)capped_side / acsy), std::ceil((double)std::max(gl.max_radius_cells, 0.0f))));
         rows += 1.0;                                                 // rounding of the end points
         rows = std::min<double>(rows, cfg.grid.tile_height - 1);
         *rows_needed = (int)rows;
@@ -430,8 +456,10 @@ struct Pipeline::Impl {
             const void* dv = nullptr;
             s = f32_channel(gr.value_channel, &dv);
             if (!s.ok()) return s;
+            // 2: the planes are still undefined -- the scatter defines every cell of the state window itself (the binned
+            // Point path at no extra pass, every other path by filling first); 1: identity-filled, nothing accumulated yet
+            pcr_hip_engine_planes_fresh(engine, !gr.defined ? 2 : (gr.fresh && gr.glyph.type == GlyphType::Point ? 1 : 0));
             if (gr.glyph.type == GlyphType::Point) {
-                if (gr.fresh) pcr_hip_engine_planes_fresh(engine, 1);
                 gr.fresh = false;
                 s = detail::hip_status(pcr_hip_scatter_point(
                     engine, gr.mask, &gr.view, static_cast<const double*>(dx), static_cast<const double*>(dy),
@@ -463,6 +491,7 @@ struct Pipeline::Impl {
             }
             gr.fresh = false;
             if (!s.ok()) return s;
+            gr.defined = true;               // (n > 0 here: the scatter ran)
         }
         // host arrays may be reused by the caller as soon as we return (ingest_async: page-locked arrays are
         // read by the DMA engine later, the caller keeps them alive until synchronize())
@@ -520,6 +549,10 @@ struct Pipeline::Impl {
         if (!result) {
             Status as = allocate_result();
             if (!as.ok()) return as;
+        }
+        {
+            Status ds = define_all_planes();          // a group no cloud ever reached
+            if (!ds.ok()) return ds;
         }
         uint32_t* d_touched = nullptr;
         Status s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, nullptr, nullptr));
@@ -604,6 +637,10 @@ struct Pipeline::Impl {
     // host copies of every group's planes + the touched flags
     Status download_state(std::vector<std::vector<float>> (&hp)[4], std::vector<uint32_t>& touched) {
         const size_t cells = (size_t)hg.width * hg.height;
+        {
+            Status ds = define_all_planes();
+            if (!ds.ok()) return ds;
+        }
         for (int p = 0; p < 4; ++p) hp[p].assign(groups.size(), {});
         for (size_t gi = 0; gi < groups.size(); ++gi)
             for (int p = 0; p < 4; ++p) {
@@ -828,6 +865,10 @@ int Pipeline::state_row_count() const { return impl_->hg.state_rows; }
 
 std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
     std::vector<PlaneView> out;
+    {
+        Impl::DeviceScope dev(impl_->cfg.cuda_device_id);
+        (void)impl_->define_all_planes();               // the caller reads (and may write) them: identity where nothing was ingested
+    }
     for (auto& g : impl_->groups) g.fresh = false;      // mutable pointers leave the pipeline: assume the planes get written
     for (size_t g = 0; g < impl_->groups.size(); ++g)
         for (int p = 0; p < 4; ++p)

@@ -2,6 +2,8 @@
 #include "pcr/engine/sharded_pipeline.h"
 
 #include <algorithm>
+#include <cstdint>
+#include <string>
 #include <vector>
 
 #include "buffer.h"
@@ -54,6 +56,24 @@ std::unique_ptr<ShardedPipeline> ShardedPipeline::create(PipelineConfig cfg, con
         const int b0 = row_block(r, world, cfg.grid.height, align).first;
         if (b0 % th != 0 && b0 < cfg.grid.height) sp->tiles_local_ = false;
     }
+    // Feasibility is decided from EVERY rank's block, so that create fails on every rank or on none (the same
+    // configuration gives the same blocks everywhere): a rank that owns no rows, or a block shorter than the halo its
+    // neighbours keep, cannot take part in the neighbour exchange (pcr_hip_comm_halo_plan would refuse it at the first
+    // exchange -- on every rank as well; here it is refused before anything is ingested).
+    if (world > 1 && !sp->tiles_local_) {
+        for (int r = 0; r < world; ++r) {
+            const auto b = row_block(r, world, cfg.grid.height, align);
+            const int rows = b.second - b.first;
+            if (rows <= 0 || rows < sp->halo_) {
+                g_create_error = "ShardedPipeline: rank " + std::to_string(r) + " would own " + std::to_string(rows) +
+                                 " rows with a halo of " + std::to_string(sp->halo_) +
+                                 " rows: use fewer ranks, a smaller radius or tile-aligned blocks (refused on every rank)";
+                return nullptr;
+            }
+        }
+    }
+    for (const auto& r : cfg.reductions)
+        if (r.glyph.type == GlyphType::Line && !r.glyph.half_length_channel.empty()) sp->line_hl_groups_ = true;
     if (world > 1) {
         Status s = detail::hip_status(pcr_hip_comm_create(&sp->comm_, id128, rank, world, device));
         if (!s.ok()) {
@@ -69,8 +89,24 @@ ShardedPipeline::~ShardedPipeline() {
 }
 
 Status ShardedPipeline::ingest(const PointCloud& cloud) {
-    // (a per-point half_length Line group can need more halo than the shard keeps: Pipeline::ingest refuses such a
-    //  cloud before anything is accumulated; callers that must refuse TOGETHER reduce Pipeline::line_reach_rows first)
+    // A per-point half_length Line group can need more halo rows than the shard keeps.  Pipeline::ingest would refuse
+    // such a cloud -- on the ranks that hold the long segments only, while the others carry on into the exchange and wait
+    // there.  So every rank's need is reduced (MAX) first and all ranks refuse the round together.
+    if (world_ > 1 && comm_ && line_hl_groups_ && !tiles_local_) {
+        int rows = 0;
+        Status s = pipe_->line_reach_rows(cloud, &rows);
+        // (a rank whose query failed still takes part in the agreement, with a need no halo can meet)
+        int32_t need = s.ok() ? (int32_t)rows : INT32_MAX;
+        Status a = detail::hip_status(pcr_hip_comm_agree_max_i32(comm_, &need, pipe_->stream_handle()));
+        if (!a.ok()) return a;
+        if (!s.ok()) return s;
+        if (need > halo_)
+            return Status::error(StatusCode::InvalidArgument,
+                "pipeline: a Line segment of this round reaches " + std::to_string((long long)need) +
+                " rows beyond its centre row on some rank, but the row-block shards keep a halo of " + std::to_string(halo_) +
+                " rows; set PipelineConfig.shard_halo_rows >= " + std::to_string((long long)need) +
+                " on every rank, or use tile-aligned row blocks (refused on every rank, nothing was accumulated)");
+    }
     return pipe_->ingest(cloud);
 }
 

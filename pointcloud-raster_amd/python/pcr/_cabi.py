@@ -61,6 +61,11 @@ class HaloPlane(C.Structure):
     _fields_ = [("d_plane", C.c_void_p), ("kind", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
+class HaloGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "state_row0", "state_rows", "own_row0", "own_row1", "halo", "nplanes",
+                                         "kinds", "valid", "reserved_")]
+
+
 SYMBOLS = {
     "pcr_hip_last_error": None,
     "pcr_hip_abi_version": [],
@@ -84,6 +89,7 @@ SYMBOLS = {
     "pcr_hip_memcpy_h2d": [_VP, _VP, _SZ, _VP],
     "pcr_hip_memcpy_d2h": [_VP, _VP, _SZ, _VP],
     "pcr_hip_memcpy_d2d": [_VP, _VP, _SZ, _VP],
+    "pcr_hip_copy_kernel": [_VP, _VP, _SZ, C.c_int, _VP],
     "pcr_hip_memset": [_VP, C.c_int, _SZ, _VP],
     "pcr_hip_arena_create": [C.POINTER(_VP), _SZ],
     "pcr_hip_arena_destroy": [_VP],
@@ -95,12 +101,15 @@ SYMBOLS = {
     "pcr_hip_route_scatter": [_VP, _U64, C.c_int, _VP, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32), _VP],
     "pcr_hip_absmax_f32": [_VP, _U64, C.POINTER(C.c_float), _VP],
     "pcr_hip_absmax_f32_masked": [_VP, _VP, _U64, _VP, C.POINTER(C.c_float), _VP],
+    "pcr_hip_signed_max_f32_masked": [_VP, _VP, _U64, _VP, C.POINTER(C.c_float), C.POINTER(C.c_float), _VP],
     "pcr_hip_comm_available": [],
     "pcr_hip_comm_unique_id": [_VP],
     "pcr_hip_comm_create": [C.POINTER(_VP), _VP, C.c_int, C.c_int, C.c_int],
     "pcr_hip_comm_destroy": [_VP],
     "pcr_hip_comm_rank": [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "pcr_hip_comm_halo_reduce": [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP],
+    "pcr_hip_comm_halo_plan": [C.POINTER(HaloGeom), C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
+    "pcr_hip_comm_agree_max_i32": [_VP, C.POINTER(C.c_int32), _VP],
     "pcr_hip_comm_allreduce_max_u32": [_VP, _VP, C.c_int, _VP],
     "pcr_hip_comm_allreduce_sum_f64": [_VP, _VP, C.c_int, _VP],
     "pcr_hip_comm_stats": [_VP, C.POINTER(_U64), C.POINTER(_U64)],

@@ -284,6 +284,15 @@ class ShardedPipeline:
         # shared between ranks and the flags are purely local: a Point-glyph run then needs no collective at all.
         th = cfg.grid.tile_height
         self.tiles_local = all(b0 % th == 0 or b0 >= cfg.grid.height for b0, _ in self.blocks)
+        # Feasibility is decided from EVERY rank's block (the same cfg gives the same blocks on every rank), so that the
+        # constructor raises on every rank or on none: a rank that owns no rows, or a block shorter than the halo its
+        # neighbours keep, cannot take part in the neighbour exchange.  (The torch exchange re-checks per call, the native
+        # one agrees on the geometry inside every pcr_hip_comm_halo_reduce; this is the early, cheap refusal.)
+        if world > 1 and not self.tiles_local and self.halo > 0:
+            for r, (b0, b1) in enumerate(self.blocks):
+                if b1 - b0 <= 0 or b1 - b0 < self.halo:
+                    raise ValueError(f"ShardedPipeline: rank {r} would own {b1 - b0} rows with a halo of {self.halo} rows: "
+                                     "use fewer ranks, a smaller radius or tile-aligned blocks (refused on every rank)")
         if comm == "native" and world > 1:
             self._comm = _native_comm(rank, world, cfg.cuda_device_id, group)
 
@@ -323,18 +332,35 @@ class ShardedPipeline:
         A Line group with a per-point half_length channel can need more halo rows than the shard keeps; every rank's
         need is reduced (MAX) BEFORE anything is accumulated, so that all ranks refuse the round together -- one rank
         raising alone would leave the others waiting in the next collective."""
-        if self.world > 1 and self._line_hl_groups and not self.tiles_local:
+        self._agree_line_reach(cloud)
+        self.pipe.ingest(cloud)
+
+    def _agree_line_reach(self, cloud):
+        """MAX over the ranks of the rows this round's Line segments need beyond their centre row; raises on EVERY rank
+        when that exceeds the halo.  Collective (when the pipeline has a Line group with a half_length channel and the
+        blocks cut reference tiles): called by ingest() and, after routing, by ingest_unrouted()."""
+        if not (self.world > 1 and self._line_hl_groups and not self.tiles_local):
+            return
+        try:
             need = int(self.pipe.line_reach_rows(cloud))
+        except Exception:
+            need = 2 ** 31 - 1                   # a rank whose query failed still takes part: no halo meets this need
+        if self._comm is not None:
+            import ctypes as C
+            from . import _cabi as A
+            word = C.c_int32(need)
+            A.check(A.lib().pcr_hip_comm_agree_max_i32(self._comm, C.byref(word), self.pipe.stream_ptr()))
+            need = int(word.value)
+        else:
             cpu = dist.get_backend(self.group) == "gloo"
             t = torch.tensor([need], dtype=torch.int32, device="cpu" if cpu else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             need = int(t.item())
-            if need > self.halo:
-                raise RuntimeError(
-                    f"pipeline: a Line segment of this round reaches {need} rows beyond its centre row on some rank, but "
-                    f"the row-block shards keep a halo of {self.halo} rows; set PipelineConfig.shard_halo_rows >= {need} "
-                    "on every rank, or use tile-aligned row blocks (refused on every rank, nothing was accumulated)")
-        self.pipe.ingest(cloud)
+        if need > self.halo:
+            raise RuntimeError(
+                f"pipeline: a Line segment of this round reaches {need} rows beyond its centre row on some rank, but "
+                f"the row-block shards keep a halo of {self.halo} rows; set PipelineConfig.shard_halo_rows >= {need} "
+                "on every rank, or use tile-aligned row blocks (refused on every rank, nothing was accumulated)")
 
     def _engine_stream(self):
         ptr = self.pipe.stream_ptr()
@@ -357,6 +383,7 @@ class ShardedPipeline:
             mine = route_cloud(cloud, self.grid, self.blocks, self.rank, self.world, self.group, ptr)
             if not ptr:
                 torch.cuda.current_stream().synchronize()
+        self._agree_line_reach(mine)         # after routing: every rank asks about the points it will really ingest
         self.pipe.ingest(mine)
         self.pipe.synchronize()              # `mine` is freed on return
         return mine.count()

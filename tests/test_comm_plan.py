@@ -1,0 +1,148 @@
+"""The agreement step of the native halo reduce (pcr_hip_comm_halo_plan, include/pcr_hip.h) on CPU.
+
+pcr_hip_comm_halo_reduce first all-gathers what every rank brings and then judges the gathered records with this pure
+function; what is tested here is that the judgement is the SAME on every rank -- every rank posts matching sends and
+receives, or every rank refuses -- for the geometries that used to leave one rank returning alone while its neighbours
+waited in ncclRecv (blocks that differ by one unit around the halo, an empty last block, asymmetric windows).
+The reference is single-device (include/pcr/engine/pipeline.h:68): no reference test to mirror.
+"""
+import ctypes as C
+
+import pytest
+
+from conftest import load_cabi
+
+
+def geoms(A, blocks, H, halo, width=64, nplanes=2, kinds=0x21, edit=None):
+    """Records of a row-block sharding as the pipeline sizes it: state window = block +- halo, clipped to the grid."""
+    arr = (A.HaloGeom * len(blocks))()
+    for r, (b0, b1) in enumerate(blocks):
+        s0, s1 = max(0, b0 - halo), min(H, b1 + halo)
+        g = arr[r]
+        g.width, g.state_row0, g.state_rows, g.own_row0, g.own_row1 = width, s0, s1 - s0, b0, b1
+        g.halo, g.nplanes, g.kinds, g.valid = halo, nplanes, kinds, 1
+    if edit:
+        edit(arr)
+    return arr
+
+
+def plan_all(A, arr):
+    """(rc, message, (send_up, send_dn, recv_up, recv_dn)) per rank."""
+    L = A.lib()
+    out = []
+    for r in range(len(arr)):
+        v = [C.c_int(-1) for _ in range(4)]
+        rc = L.pcr_hip_comm_halo_plan(arr, len(arr), r, *[C.byref(x) for x in v])
+        out.append((rc, L.pcr_hip_last_error().decode(), tuple(x.value for x in v)))
+    return out
+
+
+def row_block(rank, world, height, align=1):
+    units = (height + align - 1) // align
+    base, extra = divmod(units, world)
+    u0 = rank * base + min(rank, extra)
+    u1 = u0 + base + (1 if rank < extra else 0)
+    return min(u0 * align, height), min(u1 * align, height)
+
+
+def test_balanced_blocks_every_send_has_its_receive():
+    A = load_cabi()
+    for world, H, halo in ((2, 64, 4), (3, 100, 7), (8, 16384, 4), (5, 103, 20)):
+        blocks = [row_block(r, world, H) for r in range(world)]
+        res = plan_all(A, geoms(A, blocks, H, halo))
+        assert all(rc == 0 for rc, _, _ in res), res
+        for r in range(world):
+            su, sd, ru, rd = res[r][2]
+            assert su == (min(halo, blocks[r][0]) if r > 0 else 0)
+            assert sd == (min(halo, H - blocks[r][1]) if r < world - 1 else 0)
+            if r > 0:
+                assert ru == res[r - 1][2][1] and su == res[r - 1][2][3]          # my receive = its send, my send = its receive
+            if r < world - 1:
+                assert rd == res[r + 1][2][0] and sd == res[r + 1][2][2]
+
+
+def test_blocks_that_differ_by_one_row_around_the_halo_are_refused_by_every_rank():
+    """H = 1005 over 100 ranks: blocks of 11 and 10 rows, halo 11.  The 10-row ranks used to return alone."""
+    A = load_cabi()
+    world, H, halo = 100, 1005, 11
+    blocks = [row_block(r, world, H) for r in range(world)]
+    assert {b1 - b0 for b0, b1 in blocks} == {10, 11}
+    res = plan_all(A, geoms(A, blocks, H, halo))
+    assert all(rc == 1 for rc, _, _ in res)
+    assert len({msg for _, msg, _ in res}) == 1 and "shorter than" in res[0][1]
+    # one row less of halo and everybody goes ahead
+    assert all(rc == 0 for rc, _, _ in plan_all(A, geoms(A, blocks, H, 10)))
+
+
+def test_an_empty_last_block_is_refused_by_every_rank():
+    A = load_cabi()
+    world, H = 4, 96
+    blocks = [row_block(r, world, H, align=32) for r in range(world)]          # 3 units of 32 rows over 4 ranks
+    assert blocks[-1][0] == blocks[-1][1]
+    res = plan_all(A, geoms(A, blocks, H, 4))
+    assert all(rc == 1 for rc, _, _ in res) and all("owns no rows" in msg for _, msg, _ in res)
+
+
+def test_mismatched_windows_both_neighbours_refuse():
+    """Rank 1 keeps a taller state window than its halo allows / a different halo / width: BOTH ranks of the edge (and
+    every other rank) must refuse -- the old code posted a receive of min(halo, rows) on one side and a send of a
+    different size on the other."""
+    A = load_cabi()
+    blocks = [(0, 32), (32, 64)]
+
+    def taller(arr):
+        arr[1].state_row0, arr[1].state_rows = 32 - 9, 32 + 9                 # 9 apron rows with a halo of 4
+
+    def other_halo(arr):
+        arr[1].halo = 5
+
+    def other_width(arr):
+        arr[0].width = 128
+
+    def other_planes(arr):
+        arr[1].nplanes, arr[1].kinds = 1, 0x1
+
+    def gap(arr):
+        arr[1].own_row0 = 33
+
+    def poisoned(arr):
+        arr[0].valid = 0
+
+    for edit, word in ((taller, "more than the halo"), (other_halo, "where rank 0 brings"), (other_width, "where rank 0 brings"),
+                       (other_planes, "where rank 0 brings"), (gap, "not contiguous"), (poisoned, "invalid arguments")):
+        res = plan_all(A, geoms(A, blocks, 64, 4, edit=edit))
+        assert [rc for rc, _, _ in res] == [1, 1], (edit.__name__, res)
+        assert all(word in msg for _, msg, _ in res), (edit.__name__, res)
+        assert all(v == (0, 0, 0, 0) for _, _, v in res)
+
+
+def test_asymmetric_but_consistent_windows_are_planned_from_what_the_sender_holds():
+    """A sender whose apron is SHORTER than the halo (its window is clipped) is fine: the receive is sized from the sender's
+    record, not from min(halo, rows)."""
+    A = load_cabi()
+
+    def clipped(arr):
+        arr[0].state_rows = 32 + 2                 # rank 0 keeps only 2 of the 4 rows below its block
+
+    res = plan_all(A, geoms(A, [(0, 32), (32, 64)], 64, 4, edit=clipped))
+    assert [rc for rc, _, _ in res] == [0, 0]
+    assert res[0][2] == (0, 2, 0, 4) and res[1][2] == (4, 0, 2, 0)
+
+
+def test_nothing_to_move_is_agreed_not_assumed():
+    A = load_cabi()
+    blocks = [(0, 32), (32, 64)]
+    for halo, nplanes in ((0, 2), (4, 0)):
+        res = plan_all(A, geoms(A, blocks, 64, halo, nplanes=nplanes, kinds=0x21 if nplanes else 0))
+        assert all(rc == 0 and v == (0, 0, 0, 0) for rc, _, v in res)
+
+
+def test_argument_checks():
+    A = load_cabi()
+    L = A.lib()
+    arr = geoms(A, [(0, 32), (32, 64)], 64, 4)
+    v = [C.c_int(0) for _ in range(4)]
+    assert L.pcr_hip_comm_halo_plan(arr, 2, 2, *[C.byref(x) for x in v]) == 1
+    assert L.pcr_hip_comm_halo_plan(None, 2, 0, *[C.byref(x) for x in v]) == 1
+    word = C.c_int32(3)
+    assert L.pcr_hip_comm_agree_max_i32(None, C.byref(word), None) == 1

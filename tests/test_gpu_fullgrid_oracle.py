@@ -1,0 +1,175 @@
+"""The two Point clouds bench.py times, at FULL size, against the oracle over EVERY cell of the 4096^2 grid (VERDICT r03,
+weak 2: the full-size oracle checks were windows).  The oracle's direct ingest of 50 M points takes ~10-20 s per
+reduction on the host, so these two tests are the slow end of the GPU suite (~1.5 min together).
+
+Also here: the state initialisation that round 4 moved INSIDE ingest (planes are allocated at create but left undefined;
+the first scatter defines every cell) -- on poisoned memory, with sparse clouds (identity stored for empty LDS tiles), with
+a bin the scan has to split, on every path.  Reference semantics: tile state is initialised on first acquire inside ingest
+(src/engine/tile_manager.cpp:272-320, src/engine/pipeline.cpp:688-691)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pcr
+import pcr_oracle_py as O
+from conftest import assert_band_close, load_cabi
+from test_gpu_configs_c3_c4_c5 import bands, clustered
+from test_gpu_pipeline_api import cloud_from, config_for, spec
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_full_size_every_cell_vs_oracle():
+    """BASELINE configs[1]: 50 M uniform points (bench.py's seed), 4096^2, Sum + Count + Average: Count bit-exact, Sum and
+    Average within 1e-5 of the double-accumulated oracle, Sum = 0.0 / Average = NaN on empty cells -- all 16.8 M cells."""
+    G, n = 4096, 50_000_000
+    rng = np.random.default_rng(42)                                 # bench.py make_points("C2", ...)
+    x, y = rng.uniform(2, G - 2, n), rng.uniform(2, G - 2, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G))
+    p = pcr.Pipeline.create(config_for(og, [spec("Sum"), spec("Count"), spec("Average")], scatter_path=0))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    assert p.last_scatter()["path"] == "binned" and p.last_scatter()["points_valid"] == n
+    sm, ct, av = bands(p)
+    del p
+    want_c = O.run(og, O.COUNT, x, y, v)
+    assert np.array_equal(np.nan_to_num(want_c), np.nan_to_num(ct)) and np.array_equal(np.isnan(want_c), np.isnan(ct)), \
+        "C2 50M: Count differs from the oracle somewhere on the grid"
+    occ = ~np.isnan(want_c) & (want_c > 0)
+    assert np.nansum(ct.astype(np.float64)) == n
+    want_s = O.run(og, O.SUM, x, y, v, wide=True).astype(np.float64)
+    assert (np.abs(sm[occ].astype(np.float64) - want_s[occ]) <= 1e-5 * np.maximum(1.0, np.abs(want_s[occ]))).all()
+    assert (sm[~occ] == 0.0).all()                                  # Q2: Sum of an empty cell of a touched tile
+    del want_s
+    want_a = O.run(og, O.AVERAGE, x, y, v, wide=True).astype(np.float64)
+    assert np.array_equal(np.isnan(av), ~occ)
+    assert (np.abs(av[occ].astype(np.float64) - want_a[occ]) <= 1e-5 * np.maximum(1.0, np.abs(want_a[occ]))).all()
+
+
+def test_c4_full_size_every_cell_vs_oracle():
+    """BASELINE configs[3]: 50 M clustered points (10 000 hotspots, bench.py's recipe), 4096^2, Max + Min + Count: all three
+    bit-exact against the oracle over all 16.8 M cells, NaN mask included."""
+    G, n = 4096, 50_000_000
+    x, y, v = clustered(n, G, seed=42)
+    og = O.make_grid((0, 0, G, G))
+    p = pcr.Pipeline.create(config_for(og, [spec("Max"), spec("Min"), spec("Count")], scatter_path=0))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    assert p.last_scatter()["path"] == "binned" and p.last_scatter()["points_valid"] == n
+    mx, mn, ct = bands(p)
+    del p
+    for got, rtype, name in ((ct, O.COUNT, "count"), (mx, O.MAX, "max"), (mn, O.MIN, "min")):
+        want = O.run(og, rtype, x, y, v)
+        assert np.array_equal(got, want, equal_nan=True), f"C4 50M: {name} differs from the oracle somewhere on the grid"
+
+
+# ---- state initialisation inside ingest ---------------------------------------------------------------------------
+
+def poison_device_memory(nbytes):
+    """Leaves `nbytes` of freed device memory holding 0xFF bytes (NaNs as floats): what a pipeline's planes are carved from
+    next must not be read before it is defined."""
+    A = load_cabi()
+    L = A.lib()
+    ptr = C.c_void_p()
+    A.check(L.pcr_hip_malloc(C.byref(ptr), nbytes))
+    A.check(L.pcr_hip_memset(ptr, 0xFF, nbytes, None))
+    A.check(L.pcr_hip_device_synchronize())
+    A.check(L.pcr_hip_free(ptr))
+
+
+ALL6 = ["Sum", "Count", "Average", "Max", "Min"]
+
+
+def check_point_bands(p, og, x, y, v, names):
+    rmap = {"Sum": O.SUM, "Count": O.COUNT, "Average": O.AVERAGE, "Max": O.MAX, "Min": O.MIN}
+    for got, name in zip(bands(p), names):
+        want = O.run(og, rmap[name], x, y, v, wide=name in ("Sum", "Average"))
+        if name in ("Sum", "Average"):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), name
+            m = ~np.isnan(want)
+            assert (np.abs(got[m].astype(np.float64) - want[m]) <= 1e-5 * np.maximum(1.0, np.abs(want[m]))).all(), name
+        else:
+            assert np.array_equal(got, want, equal_nan=True), name
+
+
+@pytest.mark.parametrize("path", [0, 1, 2], ids=["auto", "direct", "binned"])
+def test_undefined_planes_are_defined_by_the_first_scatter_sparse_cloud(path):
+    """A sparse cloud: most LDS tiles receive no point at all, so the binned path has to store identity values for them
+    (empty work items), the direct path has to fill first.  The planes are carved from poisoned memory."""
+    G, n = 1024, 40_000
+    rng = np.random.default_rng(7)
+    x = rng.uniform(100, 300, n)                                     # a 200 x 200 corner of the grid
+    y = rng.uniform(G - 300, G - 100, n)
+    v = rng.uniform(-1, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G), tile=(256, 256))
+    poison_device_memory(5 * G * G * 4)
+    p = pcr.Pipeline.create(config_for(og, [spec(t) for t in ALL6], scatter_path=path))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    check_point_bands(p, og, x, y, v, ALL6)
+    # a second ingest accumulates onto what the first one defined
+    p2 = pcr.Pipeline.create(config_for(og, [spec(t) for t in ALL6], scatter_path=path))
+    p2.ingest(cloud_from(x[:n // 2], y[:n // 2], {"value": v[:n // 2]}, "device"))
+    p2.ingest(cloud_from(x[n // 2:], y[n // 2:], {"value": v[n // 2:]}, "device"))
+    p2.finalize()
+    check_point_bands(p2, og, x, y, v, ALL6)
+
+
+def test_undefined_planes_with_a_bin_the_scan_has_to_split():
+    """More than 2^17 records in one LDS tile: the tile's work items merge with atomics, which need defined cells -- the
+    conditional fill (k_fill_if) runs, and the other tiles' cells are still right."""
+    G, n = 1024, 600_000
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(500, 510, n - 5000), rng.uniform(2, G - 2, 5000)])      # one hot spot + a thin background
+    y = np.concatenate([rng.uniform(500, 510, n - 5000), rng.uniform(2, G - 2, 5000)])
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G))
+    poison_device_memory(5 * G * G * 4)
+    p = pcr.Pipeline.create(config_for(og, [spec(t) for t in ALL6], scatter_path=2))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    assert p.last_scatter()["path"] == "binned"
+    check_point_bands(p, og, x, y, v, ALL6)
+
+
+def test_finalize_and_state_planes_of_a_pipeline_that_ingested_nothing():
+    G = 512
+    og = O.make_grid((0, 0, G, G))
+    poison_device_memory(4 * G * G * 4)
+    p = pcr.Pipeline.create(config_for(og, [spec("Sum"), spec("Max")], scatter_path=0))
+    p.finalize()
+    for b in bands(p):
+        assert np.isnan(b).all()                                     # no tile touched (Q3)
+    p = pcr.Pipeline.create(config_for(og, [spec("Sum"), spec("Max")], scatter_path=0))
+    import torch
+    views = [torch.as_tensor(pcr.DeviceArrayView(ptr, (p.state_row_count(), G), "<f4", owner=p), device="cuda").cpu().numpy()
+             for ptr, kind, _ in p.state_planes()]
+    assert (views[0] == 0.0).all() and (views[1] == np.float32(-3.402823466e+38)).all()
+
+
+@pytest.mark.parametrize("glyph", ["gauss_cells", "gauss_moments", "line"])
+def test_undefined_planes_glyph_paths_fill_first(glyph):
+    G, n = 768, 60_000
+    rng = np.random.default_rng(3)
+    x, y = rng.uniform(40, 200, n), rng.uniform(G - 200, G - 40, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G))
+    if glyph == "line":
+        sp = pcr.line_splat_spec("value", default_direction=0.7, default_half_length=6.0, max_radius_cells=8.0)
+        ogl = O.make_glyph(O.GLYPH_LINE, direction=0.7, half_length=6.0, max_radius=8.0)
+    else:
+        sigma, mr = (1.0, 4.0) if glyph == "gauss_cells" else (4.0, 12.0)
+        sp = pcr.gaussian_splat_spec("value", default_sigma=sigma, max_radius_cells=mr)
+        ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=sigma, sigma_y=sigma, max_radius=mr)
+    poison_device_memory(4 * G * G * 4)
+    p = pcr.Pipeline.create(config_for(og, [sp], scatter_path=2 if glyph != "gauss_moments" else 3))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    got = bands(p)[0]
+    want = O.run(og, O.WEIGHTED_AVERAGE, x, y, v, glyph=ogl, wide=True)
+    assert (np.isnan(got) != np.isnan(want)).sum() <= 2
+    m = ~np.isnan(got) & ~np.isnan(want)
+    assert m.sum() > 1000
+    assert (np.abs(got[m].astype(np.float64) - want[m]) <= 1e-6 + 1e-4 * np.abs(want[m])).all()

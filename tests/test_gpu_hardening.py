@@ -72,6 +72,56 @@ def test_sharded_line_with_per_point_half_length_is_refused_or_exact():
     assert_band_close(got, want, rtol=1e-5, atol=1e-5, what="two shards, per-point half_length, raised halo")
 
 
+def test_sharded_line_reach_keeps_the_sign_of_half_length():
+    """The reference caps hy = half_length / cell_size_y with std::min(hy, cap) (glyph_kernels.cu:228-234): only the sign of
+    half_length that makes hy POSITIVE is capped by max_radius_cells; the other one reaches |half_length / cell_size_y| rows.
+    The shard's reach check must tell the two apart (it reduced max |hl| and lost the sign)."""
+    G, n = 128, 4000
+    rng = np.random.default_rng(5)
+    x, y = rng.uniform(30, G - 30, n), rng.uniform(30, G - 30, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    d = rng.uniform(0, np.pi, n).astype(np.float32)
+    hl_pos = rng.uniform(10.0, 20.0, n).astype(np.float32)
+    hl_neg = (-hl_pos).astype(np.float32)
+    ls = pcr.line_splat_spec("value", direction_channel="direction", half_length_channel="half_length",
+                             default_half_length=2.0, max_radius_cells=4.0)
+    ls.type = pcr.ReductionType.Sum
+    far = int(np.ceil(float(hl_pos.max()))) + 1
+
+    def reach(og, hl):
+        p = pcr.Pipeline.create(config_for(og, [ls], shard_row_begin=0, shard_row_end=50))
+        assert p.halo_rows() == 5
+        return p.line_reach_rows(cloud_from(x, y, {"value": v, "direction": d, "half_length": hl}, "device"))
+
+    north, south = O.make_grid((0, 0, G, G)), O.make_grid((0, 0, G, G), cell=(1.0, 1.0))
+    assert reach(north, hl_pos) == far          # hy < 0: never capped
+    assert reach(north, hl_neg) == 5            # hy > 0: capped at max_radius_cells = 4 (+ 1 for the end points' rounding)
+    assert reach(south, hl_pos) == 5
+    assert reach(south, hl_neg) == far
+    # the capped side really is capped: two north-up shards with the DEFAULT halo of 5 rows add up to the unsharded oracle
+    A = load_cabi()
+    L = A.lib()
+    cloud = cloud_from(x, y, {"value": v, "direction": d, "half_length": hl_neg}, "device")
+    want = O.run(north, O.SUM, x, y, v, glyph=O.make_glyph(O.GLYPH_LINE, half_length=2.0, max_radius=4.0),
+                 direction=d, half_length=hl_neg)
+    shards = []
+    for r0, r1 in ((0, 50), (50, 128)):
+        q = pcr.Pipeline.create(config_for(north, [ls], shard_row_begin=r0, shard_row_end=r1))
+        q.ingest(cloud)
+        q.synchronize()
+        shards.append(q)
+    top, bot = shards
+    halo, row = 5, G * 4
+    for (tp, kind, _), (bp, _, _) in zip(top.state_planes(), bot.state_planes()):
+        A.check(L.pcr_hip_plane_merge(kind, C.c_void_p(bp + halo * row), C.c_void_p(tp + 50 * row), halo * G, None))
+        A.check(L.pcr_hip_plane_merge(kind, C.c_void_p(tp + (50 - halo) * row), C.c_void_p(bp), halo * G, None))
+    A.check(L.pcr_hip_device_synchronize())
+    for q in shards:
+        q.finalize()
+    got = np.vstack([np.array(top.result().band_array(0)), np.array(bot.result().band_array(0))])
+    assert_band_close(got, want, rtol=1e-5, atol=1e-5, what="two shards, negative half_length (capped side), default halo")
+
+
 def test_two_threads_two_pipelines_share_the_scratch_arena_safely():
     """the arena was only safe for one host thread.  Two threads hammer two pipelines on one device
     (binned path: both borrow the device-wide scratch on every ingest); every result must equal the oracle."""
