@@ -166,6 +166,9 @@ k_cell_gauss(GridDev g, BinGeom b, CellGauss P, PlanesDev pl, const uint4* __res
     for (int k = 0; k < kRecPerThread; ++k) {
         const unsigned j = threadIdx.x + k * kTileThreads;
         rc[k] = j < it.count ? rec[j] : make_uint4(kNullCell, 0u, 0u, 0u);
+        // a record is only ever trusted as far as the tile goes: a local cell outside it (a record written for another tile
+        // geometry, a slot the scatter pass never filled) is dropped here instead of indexing the LDS arrays below
+        if (rc[k].x >= (unsigned)cells) rc[k].x = kNullCell;
     }
     for (int i = threadIdx.x; i <= cells; i += kTileThreads) off[i] = 0;
     {
@@ -386,6 +389,14 @@ bool plan_cells(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, Cell
     p.tile_h = best_h;
     p.P.cap = best_cap;
     p.lds = (size_t)64 * (best_h + 2 * r) * 8 * planes + (((size_t)p.tile_w * best_h + 1 + 3) & ~size_t(3)) * 4 + (size_t)best_cap * 12;
+    // The bounds every LDS index of k_cell_gauss rests on (the r03c aperture violation, DESIGN section 9, was a launch of
+    // this kernel's 512-thread, 40-row shape from an uncommitted experiment; the record names no address, so every bound
+    // is pinned here instead of being implied):
+    //   an item holds <= cap records and the kernel keeps <= kRecPerThread x THREADS of them in registers;
+    //   the in-LDS scan walks <= 8 cells per thread; the carve-up ends inside the CU's 160 KB with the static words.
+    const int rec_per_thread = p.threads == 1024 ? 8 : 16;
+    if (best_cap <= 0 || best_cap > rec_per_thread * p.threads) return false;
+    if (p.lds + 64 > (size_t)160 * 1024 || fixed + (size_t)best_cap * 12 != p.lds) return false;
     *out = p;
     return true;
 }

@@ -173,3 +173,34 @@ def test_undefined_planes_glyph_paths_fill_first(glyph):
     m = ~np.isnan(got) & ~np.isnan(want)
     assert m.sum() > 1000
     assert (np.abs(got[m].astype(np.float64) - want[m]) <= 1e-6 + 1e-4 * np.abs(want[m])).all()
+
+
+def test_cell_tiles_at_the_launch_shape_of_the_r03c_fault(monkeypatch):
+    """gpurun_out/r03c (round 3, an uncommitted experiment) recorded HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in
+    k_cell_gauss<3, 3, 1, 512>: grid 13 417 workgroups of 512 threads, 154 740 B of group segment = 40-row tiles, 8 192
+    records per item, 50 M points on 4096^2, sigma = 1.  The committed kernel still has that shape (PCR_HIP_CELL_TILE_H = 40,
+    and by itself on windows with more 20-row tiles than one binning pass takes): run exactly that launch and check it
+    against the oracle (what the record can and cannot tell)."""
+    monkeypatch.setenv("PCR_HIP_CELL_TILE_H", "40")
+    G, n = 4096, 50_000_000
+    rng = np.random.default_rng(42)
+    x, y = rng.uniform(2, G - 2, n), rng.uniform(2, G - 2, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G))
+    gs = pcr.gaussian_splat_spec("value", default_sigma=1.0, max_radius_cells=4.0)
+    p = pcr.Pipeline.create(config_for(og, [gs], scatter_path=0, gpu_pool_size_bytes=24 * n + (64 << 20)))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    p.finalize()
+    info = p.last_scatter()
+    assert info["path"] == "binned" and tuple(info["lds_tile"]) == (58, 40) and info["num_bins"] == 7313, info
+    assert info["points_valid"] == n
+    got = bands(p)[0]
+    del p
+    lo, hi, reach = 2010, 2138, 3
+    sel = (x >= lo - reach - 1) & (x < hi + reach + 1) & (y > G - hi - reach - 1) & (y <= G - lo + reach + 1)
+    ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=1.0, sigma_y=1.0, max_radius=4.0)
+    want = O.run(og, O.WEIGHTED_AVERAGE, x[sel], y[sel], v[sel], glyph=ogl, wide=True)[lo:hi, lo:hi].astype(np.float64)
+    g = got[lo:hi, lo:hi]
+    assert not np.isnan(g).any() and not np.isnan(want).any()
+    assert (np.abs(g.astype(np.float64) - want) <= 1e-4 * np.maximum(1e-3, np.abs(want))).all()
+    assert np.isfinite(got).all()                                    # every cell of the grid is reached at ~3 points per cell
