@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <filesystem>
 #include <map>
+#include <mutex>
+#include <set>
 #include <vector>
 
 namespace pcr {
@@ -134,15 +136,62 @@ struct Pipeline::Impl {
             if (!registered(r.type))
                 return Status::error(StatusCode::InvalidArgument, "pipeline: unknown reduction type");
 
+        // The reference's GPU-initialisation matrix (src/engine/pipeline.cpp:108-162), with its exact messages and status
+        // codes.  Where the reference goes on in CPU mode, this build prints the reference's line and then refuses: it
+        // contains no CPU engine, and a silent CPU path behind the GPU API is exactly what it must not have.
+        auto no_cpu_engine = [](const char* how) {
+            return Status::error(StatusCode::NotImplemented,
+                std::string("pipeline: ") + how + ", but this build contains only the MI355X HIP engine (no CPU engine to "
+                "continue on); set gpu_require_strict to get the reference's own error instead");
+        };
         int ndev = 0;
         pcr_hip_device_count(&ndev);
-        if (ndev <= 0)
-            return Status::error(StatusCode::CudaError,
-                "pipeline: no HIP device available (and no CPU engine to fall back to)");
-        if (cfg.cuda_device_id < 0 || cfg.cuda_device_id >= ndev)
+        if (ndev <= 0) {
+            const std::string msg = "No CUDA-capable GPU detected";
+            if (cfg.exec_mode == ExecutionMode::Auto) {
+                std::fprintf(stderr, "Info: %s - using CPU mode\n", msg.c_str());                       // pipeline.cpp:130
+                return no_cpu_engine("Auto mode found no GPU and the reference would use its CPU mode");
+            }
+            if (cfg.gpu_require_strict)
+                return Status::error(StatusCode::CudaError, msg + " - GPU mode requested but no GPU available");   // :118-119
+            if (cfg.gpu_fallback_to_cpu) {
+                std::fprintf(stderr, "Warning: %s - falling back to CPU mode\n", msg.c_str());          // :122
+                return no_cpu_engine("the reference would fall back to its CPU mode here");
+            }
+            return Status::error(StatusCode::CudaError, msg + " - GPU required but not available");         // :125-126
+        }
+        Status s = Status::success();
+        if (cfg.cuda_device_id >= 0) {
+            const int rc = cfg.cuda_device_id < ndev ? pcr_hip_set_device(cfg.cuda_device_id) : PCR_HIP_INVALID_ARGUMENT;
+            if (rc != PCR_HIP_OK) {
+                const std::string err_msg = "Failed to set CUDA device " + std::to_string(cfg.cuda_device_id) + ": " +
+                                            (cfg.cuda_device_id < ndev ? std::string(pcr_hip_last_error()) : std::string("invalid device ordinal"));   // :136-137
+                if (cfg.gpu_require_strict) return Status::error(StatusCode::CudaError, err_msg);          // :141
+                if (cfg.gpu_fallback_to_cpu) {
+                    std::fprintf(stderr, "Warning: %s - falling back to CPU mode\n", err_msg.c_str());   // :143
+                    return no_cpu_engine("the reference would fall back to its CPU mode here");
+                }
+                return Status::error(StatusCode::CudaError, err_msg);                                      // :146
+            }
+        } else {
             return Status::error(StatusCode::InvalidArgument, "pipeline: invalid device id");
-        Status s = detail::hip_status(pcr_hip_set_device(cfg.cuda_device_id));
-        if (!s.ok()) return s;
+        }
+        {
+            // pipeline.cpp:149-160, once per device and process (the reference prints it at every create; a bench that
+            // creates a pipeline per step would bury its own output)
+            static std::mutex mu;
+            static std::set<int> announced;
+            std::lock_guard<std::mutex> lock(mu);
+            if (announced.insert(cfg.cuda_device_id).second) {
+                const std::string name = cuda_device_name(cfg.cuda_device_id);
+                size_t free_mem = 0, total_mem = 0;
+                if (cuda_get_memory_info(&free_mem, &total_mem, cfg.cuda_device_id))
+                    std::fprintf(stderr, "Info: Using GPU %d: %s (%.1f GB free / %.1f GB total)\n", cfg.cuda_device_id, name.c_str(),
+                                 free_mem / (1024.0 * 1024.0 * 1024.0), total_mem / (1024.0 * 1024.0 * 1024.0));
+                else
+                    std::fprintf(stderr, "Info: Using GPU %d: %s\n", cfg.cuda_device_id, name.c_str());
+            }
+        }
         if (cfg.use_cuda_streams) {
             s = detail::hip_status(pcr_hip_stream_create(&stream));
             if (!s.ok()) return s;
@@ -190,8 +239,19 @@ struct Pipeline::Impl {
         hg.state_row0 = std::max(0, r0 - halo);
         hg.state_rows = std::min(g.height, r1 + halo) - hg.state_row0;
 
-        s = detail::hip_status(pcr_hip_engine_create(&engine, &hg, cfg.gpu_pool_size_bytes, stream));   // arena pre-sized at create, like the reference's MemoryPool
-        if (!s.ok()) return s;
+        {
+            // arena pre-sized at create, like the reference's MemoryPool; a pool that cannot be created follows the
+            // reference's matrix too (src/engine/pipeline.cpp:181-192)
+            const int rc = pcr_hip_engine_create(&engine, &hg, cfg.gpu_pool_size_bytes, stream);
+            if (rc == PCR_HIP_OUT_OF_MEMORY) {
+                const std::string err_msg = "Failed to create GPU memory pool";
+                if (cfg.gpu_require_strict || !cfg.gpu_fallback_to_cpu) return Status::error(StatusCode::OutOfMemory, err_msg);
+                std::fprintf(stderr, "Warning: %s - falling back to CPU mode\n", err_msg.c_str());
+                return no_cpu_engine("the reference would fall back to its CPU mode here");
+            }
+            s = detail::hip_status(rc);
+            if (!s.ok()) return s;
+        }
         s = detail::hip_status(pcr_hip_engine_set_path(engine, cfg.scatter_path));
         if (!s.ok()) return s;
 

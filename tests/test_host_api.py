@@ -166,10 +166,27 @@ def test_pipeline_create_fails_loudly_without_engine(capfd):
     assert "ExecutionMode::CPU is not available" in pcr.pipeline_create_error()
     assert "Error:" in capfd.readouterr().err
     if pcr.device_count() == 0:
+        # The reference's GPU-initialisation matrix (src/engine/pipeline.cpp:108-131; tests/cpp/test_error_handling.cpp:
+        # 111-163), message for message and code for code -- except that where the reference continues in CPU mode this
+        # build prints the reference's line and then refuses (it has no CPU engine).
+        msg = "No CUDA-capable GPU detected"
         cfg.exec_mode = pcr.ExecutionMode.Auto
-        cfg.gpu_fallback_to_cpu = True                          # ignored by design
         assert pcr.Pipeline.create(cfg) is None
-        assert "no HIP device" in pcr.pipeline_create_error()
+        assert f"Info: {msg} - using CPU mode\n" in capfd.readouterr().err
+        assert "only the MI355X HIP engine" in pcr.pipeline_create_error()
+        cfg.exec_mode = pcr.ExecutionMode.GPU
+        cfg.gpu_fallback_to_cpu, cfg.gpu_require_strict = True, False            # the reference's defaults
+        assert pcr.Pipeline.create(cfg) is None
+        assert f"Warning: {msg} - falling back to CPU mode\n" in capfd.readouterr().err
+        assert "only the MI355X HIP engine" in pcr.pipeline_create_error()
+        cfg.gpu_require_strict = True                                             # GPU_StrictMode_FailsWithoutDevice
+        assert pcr.Pipeline.create(cfg) is None
+        assert pcr.pipeline_create_error().endswith(f"{msg} - GPU mode requested but no GPU available")
+        assert "Warning:" not in capfd.readouterr().err
+        cfg.gpu_fallback_to_cpu, cfg.gpu_require_strict = False, False
+        assert pcr.Pipeline.create(cfg) is None
+        assert pcr.pipeline_create_error().endswith(f"{msg} - GPU required but not available")
+        cfg.gpu_fallback_to_cpu = True
     cfg.exec_mode = pcr.ExecutionMode.GPU
     r.type = pcr.ReductionType.Median                           # not registered -> create fails (pipeline.cpp:229-233)
     cfg.reductions = [r]
