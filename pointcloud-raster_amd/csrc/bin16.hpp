@@ -20,6 +20,8 @@
 //     Chan load(uint64_t i) const;                                      issued with the x, y, v loads of a batch
 //     bool make(g, b, routed, pg, value, chan, uint4& rec) const;       fills rec.y/.z/.w; false: the record cannot hold
 //                                                                       this point -> null record + the list
+//     static constexpr bool kOwnsX;                                     false: .x = the local centre cell (set by the pass);
+//                                                                       true: make() fills .x as well (kNullCell = nothing to do)
 // Replaces tile_router_assign_gpu + tile_router_sort_gpu (src/engine/tile_router_kernels.cu:34-293) for glyph clouds.
 #pragma once
 
@@ -250,7 +252,7 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
             const Routed16 r = classify<Maker::kCentre>(g, b, i, wx[u], wy[u], pg);
             if (r.kind != 1) continue;                       // kind 2 was listed by the counting pass
             rank[k] = atomicAdd(&lds_hist[r.bin], 1u) | ((unsigned)r.bin << 16);          // rank < 2^14 (chunk), bin < 2^16
-            if (mk.make(g, b, r, pg, val[u], ch[u], rec[k])) rec[k].x = r.lcell;
+            if (mk.make(g, b, r, pg, val[u], ch[u], rec[k])) { if (!Maker::kOwnsX) rec[k].x = r.lcell; }   // (kOwnsX: the Maker filled .x itself)
             else fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;                            // the slot keeps a null record
         }
     }

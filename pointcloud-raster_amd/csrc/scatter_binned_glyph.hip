@@ -175,6 +175,7 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
 // offset (a garbage half_length: |offset| > 32000 cells) goes to the list and is walked by the direct form.
 struct LineRecMaker {
     static constexpr bool kCentre = false;
+    static constexpr bool kOwnsX = false;
     static constexpr int kPer = 12, kBatch = 6;               // the f64 sincos of the end points needs the registers
     GlyphDev gl;
     struct Chan { float dir, hl; };
@@ -257,6 +258,143 @@ k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ re
         if (s == 0.0 && c == 0u) continue;
         int ly = i / t.lw, lx = i - ly * t.lw;
         int64_t cell = (int64_t)(sink.y0 + ly - g.st_r0) * g.W + (sink.x0 + lx);
+        if ((MASK & 1) && s != 0.0) atomic_add_f32(pl.sum + cell, (float)s);
+        if ((MASK & 2) && c) atomic_add_f32(pl.wgt + cell, (float)c);
+    }
+}
+
+// ---- Line tiles on WALK-STATE records (round 4) -------------------------------------------------------------------
+// profiles/r04_line_ablation.md: k_tile_line16's walk takes 1.2 ms of vector / scalar instructions WITHOUT a single LDS
+// atomic in it -- ~20 instructions per 64-lane step (two error tests, four selects, a per-lane countdown) and ~185 per
+// batch of 64 segments for what does not depend on the step at all (the clip rectangle from two integer divisions, the
+// bounding-box test, |dx|, |dy|, the signs, a wave reduction for the longest segment).  All of the latter is a function of
+// the point alone, and the scatter pass has the point in registers: it now stores the walk's STATE instead of the end points,
+//     .x = first window cell (16) | cells to visit (8) | Bresenham remainder at the first cell (8)
+//     .y = value      .z = 2 M (8) | 2 m (8) | major step (int8) | minor step (int8)        (steps in window cells)
+// where M / m = the longer / shorter extent.  The reference's walk (glyph_kernels.cu:252-278: both error tests every step)
+// visits, as its j-th cell, major = j, minor = k_j = floor((2 j m + M - 1) / 2M) -- the two strict tests make the
+// minor axis advance exactly when 2 j m + M - 1 crosses a multiple of 2M (derivation in DESIGN section 3a; Count is
+// bit-exact against the oracle's walk on every parity case).  So the remainder r_j = (2 j m + M - 1) mod 2M is all the
+// state a step needs:   r += 2m;  if (r >= 2M) { r -= 2M; cell += major + minor } else cell += major   -- 7 instructions.
+// CLIPPING (the centre cell's reference tile, Q4) keeps a CONTIGUOUS range of j (both coordinates are monotone in j): the
+// scatter pass solves it for the few segments that cross their clip rectangle and stores the state at the first kept cell.
+// Used when the LDS apron covers the glyph's reach (default half length: every kept cell lies inside the window) and the
+// window's pitch fits an int8 step; the other cases keep the end-point records above.
+struct LineStateMaker {
+    static constexpr bool kCentre = false;
+    static constexpr bool kOwnsX = true;
+    static constexpr int kPer = 12, kBatch = 6;               // the f64 sincos of the end points needs the registers
+    GlyphDev gl;
+    int lw, lh, apron;                                        // the tile kernel's LDS window
+    struct Chan { float dir; };
+    __device__ __forceinline__ Chan load(uint64_t i) const {
+        Chan c{0.f};
+        if (gl.direction) c.dir = gl.direction[i];
+        return c;
+    }
+    // smallest j >= 0 with k_j >= k, for m > 0:  2 j m + M - 1 >= 2 M k
+    static __device__ __forceinline__ int first_j_with_k(int k, int M, int m) {
+        const int num = 2 * M * k - M + 1;
+        return num <= 0 ? 0 : (num + 2 * m - 1) / (2 * m);
+    }
+    __device__ __forceinline__ bool make(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
+                                         float val, const Chan& ch, uint4& rec) const {
+        const LineParams q = line_params(g, gl, pg, val, GlyphChan{ch.dir, 0.f, 0.f});
+        const long long ldx = llabs((long long)q.ix1 - q.ix0), ldy = llabs((long long)q.iy1 - q.iy0);
+        if (ldx > 127 || ldy > 127) return false;            // (cannot happen while the apron covers the reach: the list)
+        const int dx = (int)ldx, dy = (int)ldy;
+        const bool xmajor = dx >= dy;
+        const int M = xmajor ? dx : dy, m = xmajor ? dy : dx;
+        const int sx = q.ix0 < q.ix1 ? 1 : -1, sy = q.iy0 < q.iy1 ? 1 : -1;
+        const int by = r.bin / b.bins_x, bx = r.bin - by * b.bins_x;
+        const int wx0 = bx * b.tile_w - apron, wy0 = g.st_r0 + b.row0 + by * b.tile_h - apron;   // window origin, global cells
+        // kept cells: the clip rectangle; it must lie inside the window wherever the segment goes (else: the list)
+        const int rx0 = max(q.cx0, wx0), rx1 = min(q.cx1, wx0 + lw), ry0 = max(q.cy0, wy0), ry1 = min(q.cy1, wy0 + lh);
+        const int bx0 = min(q.ix0, q.ix1), bx1 = max(q.ix0, q.ix1), by0 = min(q.iy0, q.iy1), by1 = max(q.iy0, q.iy1);
+        int js = 0, je = M;
+        if (!(bx0 >= rx0 && bx1 < rx1 && by0 >= ry0 && by1 < ry1)) {
+            // the window must not be what cuts the segment: cells inside the clip rectangle but outside the window would be lost
+            if ((bx0 < wx0 && q.cx0 < wx0) || (bx1 >= wx0 + lw && q.cx1 > wx0 + lw) ||
+                (by0 < wy0 && q.cy0 < wy0) || (by1 >= wy0 + lh && q.cy1 > wy0 + lh)) return false;
+            // major axis: u_j = u0 + su j in [lo, hi);  minor axis: w0 + sw k_j in [lo, hi)
+            const int u0 = xmajor ? q.ix0 : q.iy0, su = xmajor ? sx : sy, ulo = xmajor ? rx0 : ry0, uhi = xmajor ? rx1 : ry1;
+            const int w0 = xmajor ? q.iy0 : q.ix0, sw = xmajor ? sy : sx, wlo = xmajor ? ry0 : rx0, whi = xmajor ? ry1 : rx1;
+            js = max(js, su > 0 ? ulo - u0 : u0 - (uhi - 1));
+            je = min(je, su > 0 ? uhi - 1 - u0 : u0 - ulo);
+            const int ka = sw > 0 ? wlo - w0 : w0 - (whi - 1), kb = sw > 0 ? whi - 1 - w0 : w0 - wlo;     // k in [ka, kb]
+            if (m == 0) {
+                if (ka > 0 || kb < 0) je = -1;
+            } else {
+                if (ka > 0) js = max(js, first_j_with_k(ka, M, m));
+                if (kb < m) je = min(je, kb < 0 ? -1 : first_j_with_k(kb + 1, M, m) - 1);
+            }
+        }
+        rec.y = __float_as_uint(val);
+        rec.w = r.lcell;
+        if (je < js) { rec.x = b16::kNullCell; rec.z = 0u; return true; }       // nothing of it is kept
+        int k = 0, rem = 0;
+        if (M > 0) {
+            const int N = 2 * js * m + M - 1;
+            k = N / (2 * M);
+            rem = N - k * 2 * M;
+        }
+        const int cx = xmajor ? q.ix0 + sx * js : q.ix0 + sx * k, cy = xmajor ? q.iy0 + sy * k : q.iy0 + sy * js;
+        const unsigned li = (unsigned)((cy - wy0) * lw + (cx - wx0));
+        const int stepA = xmajor ? sx : sy * lw, stepB = xmajor ? sy * lw : sx;
+        rec.x = li | ((unsigned)(je - js + 1) << 16) | ((unsigned)rem << 24);
+        rec.z = (unsigned)(M > 0 ? 2 * M : 1) | ((unsigned)(2 * m) << 8) | (((unsigned)stepA & 0xFFu) << 16) | ((unsigned)stepB << 24);
+        return true;
+    }
+};
+
+template <unsigned MASK>
+__global__ void __launch_bounds__(kThreads)
+k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ records,
+                const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
+    extern __shared__ double lds_win[];
+    if (blockIdx.x >= *n_items) return;
+    const BinItem it = items[blockIdx.x];
+    const int cells = t.lw * t.lh;                           // even (checked on the host)
+    double* t_s = lds_win;
+    unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
+    const uint4* rec = records + it.first;
+    uint4 cur = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        if (MASK & 1) t_s[i] = 0.0;
+        if (MASK & 2) t_c[i] = 0u;
+    }
+    __syncthreads();
+    for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
+        const unsigned jn = j0 + kThreads + threadIdx.x;
+        const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+        const bool valid = cur.x != b16::kNullCell;
+        int li = (int)(cur.x & 0xFFFFu);
+        const unsigned n = valid ? (cur.x >> 16) & 0xFFu : 0u;
+        unsigned r = cur.x >> 24;
+        const unsigned M2 = cur.z & 0xFFu, m2 = (cur.z >> 8) & 0xFFu;
+        const int stepA = (int)(signed char)((cur.z >> 16) & 0xFFu), stepAB = stepA + (int)(signed char)(cur.z >> 24);
+        const double dv = (double)__uint_as_float(cur.y);
+        for (unsigned j = 0; __any(j < n); ++j) {
+            if (j < n) {
+                if (MASK & 1) unsafeAtomicAdd(&t_s[li], dv);
+                if (MASK & 2) atomicAdd(&t_c[li], 1u);
+            }
+            r += m2;
+            const bool c = r >= M2;
+            r -= c ? M2 : 0u;
+            li += c ? stepAB : stepA;
+        }
+        cur = nxt;
+    }
+    __syncthreads();
+    const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
+    const int x0 = bx * t.bins.tile_w - t.apron, y0 = t.bins.row0 + by * t.bins.tile_h - t.apron;      // window origin; rows relative to the state window
+    for (int i = threadIdx.x; i < cells; i += kThreads) {
+        double s = (MASK & 1) ? t_s[i] : 0.0;
+        unsigned c = (MASK & 2) ? t_c[i] : 0u;
+        if (s == 0.0 && c == 0u) continue;
+        int ly = i / t.lw, lx = i - ly * t.lw;
+        int64_t cell = (int64_t)(y0 + ly) * g.W + (x0 + lx);     // non-zero cells were clipped to the grid by the scatter pass
         if ((MASK & 1) && s != 0.0) atomic_add_f32(pl.sum + cell, (float)s);
         if ((MASK & 2) && c) atomic_add_f32(pl.wgt + cell, (float)c);
     }
@@ -440,6 +578,8 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
         if (rc) return rc;
         PCR_HIP_TRY(hipMemsetAsync(e->d_scratch + L.o_fbc, 0, 4, e->stream));
         const bool covered = t.apron >= t.need && !gl.half_length;
+        // walk-state records: every kept cell lies inside the window, the window's pitch fits an int8 step
+        const bool state_records = covered && t.lw <= 127 && (t.lw * t.lh) % 2 == 0 && t.lw * t.lh <= 65536;
         for (int row0 = 0; row0 < e->gd.st_rows; row0 += band16) {
             const int rows = std::min(band16, e->gd.st_rows - row0);
             GridDev gd = e->gd;
@@ -450,17 +590,18 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
             t.bins.rows = rows;
             t.bins.bins_y = (rows + S - 1) / S;
             t.bins.nbins = t.bins.bins_x * t.bins.bins_y;
-            t.bins.chunk = b16::chunk_of<LineRecMaker>();
+            t.bins.chunk = state_records ? b16::chunk_of<LineStateMaker>() : b16::chunk_of<LineRecMaker>();
             total_bins += t.bins.nbins;
             b16::Buffers bb{};
-            rc = b16::bin(e, gd, t.bins, LineRecMaker{gl}, x, y, v, n, item_points, L, &bb);
+            if (state_records) rc = b16::bin(e, gd, t.bins, LineStateMaker{gl, t.lw, t.lh, t.apron}, x, y, v, n, item_points, L, &bb);
+            else rc = b16::bin(e, gd, t.bins, LineRecMaker{gl}, x, y, v, n, item_points, L, &bb);
             if (rc) return rc;
             ScopedKernelTimer tm(e, "k_tile_line");
             auto go = [&](auto kernel) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, t, pl, bb.records, bb.items, bb.n_items);
             };
-#define PCR_LINE16(M) if (covered) go(&k_tile_line16<M, true>); else go(&k_tile_line16<M, false>);
+#define PCR_LINE16(M) if (state_records) go(&k_tile_line_rec<M>); else if (covered) go(&k_tile_line16<M, true>); else go(&k_tile_line16<M, false>);
             switch (mask) {
                 case 1: PCR_LINE16(1) break;
                 case 2: PCR_LINE16(2) break;

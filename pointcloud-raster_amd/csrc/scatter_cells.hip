@@ -47,6 +47,7 @@ namespace {
 // f32 sub-cell offset (glyph_kernels.cu:116-117).
 struct GaussCellMaker {
     static constexpr bool kCentre = true;
+    static constexpr bool kOwnsX = false;
     static constexpr int kPer = 16, kBatch = 16;
     struct Chan {};
     __device__ __forceinline__ Chan load(uint64_t) const { return Chan{}; }
