@@ -47,13 +47,14 @@ struct Routed16 {
     int kind;
     int bin;
     unsigned lcell;
+    int bx, by;                 // the tile's column / row (bin = by * bins_x + bx): a Maker that needs the tile's origin
 };
 
 // CENTRE: the record's footprint is positioned by floor(fc), which must then be the routed cell (Gaussians; a Line
 // record carries its own end points).
 template <bool CENTRE>
 __device__ __forceinline__ Routed16 classify(const GridDev& g, const BinGeom& b, uint64_t i, double wx, double wy, PointGeom& pg) {
-    Routed16 r{0, 0, 0u};
+    Routed16 r{0, 0, 0u, 0, 0};
     pg = point_geom(g, wx, wy);
     if (!(pg.valid && point_kept(g, i))) return r;
     if (CENTRE) {
@@ -63,6 +64,8 @@ __device__ __forceinline__ Routed16 classify(const GridDev& g, const BinGeom& b,
     const int sr = pg.row - g.st_r0 - b.row0;
     const int bx = fast_div(pg.col, b.tile_w), by = fast_div(sr, b.tile_h);
     r.kind = 1;
+    r.bx = bx;
+    r.by = by;
     r.bin = by * b.bins_x + bx;
     r.lcell = (unsigned)((sr - by * b.tile_h) * b.tile_w + (pg.col - bx * b.tile_w));
     return r;

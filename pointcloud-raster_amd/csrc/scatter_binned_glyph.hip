@@ -16,6 +16,7 @@
 #include "bin16.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace pcrhip;
 
@@ -188,7 +189,7 @@ struct LineRecMaker {
     __device__ __forceinline__ bool make(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
                                          float val, const Chan& ch, uint4& rec) const {
         const LineParams q = line_params(g, gl, pg, val, GlyphChan{ch.dir, ch.hl, 0.f});
-        const int by = r.bin / b.bins_x, bx = r.bin - by * b.bins_x;
+        const int by = r.by, bx = r.bx;
         const long long ox = (long long)bx * b.tile_w, oy = (long long)g.st_r0 + b.row0 + (long long)by * b.tile_h;
         const long long a0 = q.ix0 - ox, b0 = q.iy0 - oy, a1 = q.ix1 - ox, b1 = q.iy1 - oy;
         const long long lim = 32000;
@@ -292,21 +293,29 @@ struct LineStateMaker {
         if (gl.direction) c.dir = gl.direction[i];
         return c;
     }
+    // n / d for 0 <= n < 2^17, 1 <= d < 2^9 (extents are <= 127 cells): a float product and a correction step
+    static __device__ __forceinline__ int div_small(int n, int d) {
+        int q = (int)((float)n * __frcp_rn((float)d));
+        const int r = n - q * d;
+        q += (r >= d) - (r < 0);
+        return q;
+    }
     // smallest j >= 0 with k_j >= k, for m > 0:  2 j m + M - 1 >= 2 M k
     static __device__ __forceinline__ int first_j_with_k(int k, int M, int m) {
         const int num = 2 * M * k - M + 1;
-        return num <= 0 ? 0 : (num + 2 * m - 1) / (2 * m);
+        return num <= 0 ? 0 : div_small(num + 2 * m - 1, 2 * m);
     }
     __device__ __forceinline__ bool make(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
                                          float val, const Chan& ch, uint4& rec) const {
         const LineParams q = line_params(g, gl, pg, val, GlyphChan{ch.dir, 0.f, 0.f});
-        const long long ldx = llabs((long long)q.ix1 - q.ix0), ldy = llabs((long long)q.iy1 - q.iy0);
-        if (ldx > 127 || ldy > 127) return false;            // (cannot happen while the apron covers the reach: the list)
-        const int dx = (int)ldx, dy = (int)ldy;
+        // (unsigned differences: a garbage end point -- NaN direction -- must not overflow on its way to the list)
+        const unsigned udx = (unsigned)max(q.ix0, q.ix1) - (unsigned)min(q.ix0, q.ix1), udy = (unsigned)max(q.iy0, q.iy1) - (unsigned)min(q.iy0, q.iy1);
+        if (udx > 127u || udy > 127u) return false;          // (cannot happen while the apron covers the reach: the list)
+        const int dx = (int)udx, dy = (int)udy;
         const bool xmajor = dx >= dy;
         const int M = xmajor ? dx : dy, m = xmajor ? dy : dx;
         const int sx = q.ix0 < q.ix1 ? 1 : -1, sy = q.iy0 < q.iy1 ? 1 : -1;
-        const int by = r.bin / b.bins_x, bx = r.bin - by * b.bins_x;
+        const int by = r.by, bx = r.bx;
         const int wx0 = bx * b.tile_w - apron, wy0 = g.st_r0 + b.row0 + by * b.tile_h - apron;   // window origin, global cells
         // kept cells: the clip rectangle; it must lie inside the window wherever the segment goes (else: the list)
         const int rx0 = max(q.cx0, wx0), rx1 = min(q.cx1, wx0 + lw), ry0 = max(q.cy0, wy0), ry1 = min(q.cy1, wy0 + lh);
@@ -325,17 +334,18 @@ struct LineStateMaker {
             if (m == 0) {
                 if (ka > 0 || kb < 0) je = -1;
             } else {
-                if (ka > 0) js = max(js, first_j_with_k(ka, M, m));
+                if (ka > m) je = -1;                          // (k_j never exceeds m)
+                else if (ka > 0) js = max(js, first_j_with_k(ka, M, m));
                 if (kb < m) je = min(je, kb < 0 ? -1 : first_j_with_k(kb + 1, M, m) - 1);
             }
         }
         rec.y = __float_as_uint(val);
         rec.w = r.lcell;
         if (je < js) { rec.x = b16::kNullCell; rec.z = 0u; return true; }       // nothing of it is kept
-        int k = 0, rem = 0;
-        if (M > 0) {
+        int k = 0, rem = M > 0 ? M - 1 : 0;                  // the state at j = 0 ...
+        if (js > 0) {                                        // ... and at the first kept cell of a clipped segment (M > 0 there)
             const int N = 2 * js * m + M - 1;
-            k = N / (2 * M);
+            k = div_small(N, 2 * M);
             rem = N - k * 2 * M;
         }
         const int cx = xmajor ? q.ix0 + sx * js : q.ix0 + sx * k, cy = xmajor ? q.iy0 + sy * k : q.iy0 + sy * js;
@@ -347,50 +357,105 @@ struct LineStateMaker {
     }
 };
 
+// The value plane of the window as EXACT 64-bit fixed point (ds_add_u64) where the item's values allow it.
+// tools/ubench_lds_patterns.hip: an LDS atomic wave-instruction costs ~(largest number of lanes on one bank pair) x 4 cycles
+// as ds_add_f64 and x 2 as ds_add_u64 -- with the walk down to 7 instructions a step the kernel is bound by exactly that
+// (64 segments of a wave stand on 64 unrelated cells: ~5.4 lanes on the fullest bank pair).  A float is an integer multiple
+// of 2^(E - 150) (E its biased exponent), so every value whose exponent lies in [E_lo, E_lo + 22] is an exact integer
+// multiple q < 2^46 of 2^(E_lo - 150), and 65 536 of them (the most an item holds) sum without overflow in 63 bits: the
+// sum is EXACT, rounded once when it is merged (the f64 plane rounds every add).  E_lo is guessed from the item's first
+// 1024 values (their largest exponent + 3 at the top of the range: room for values 8 x larger, and down to 2^-19 of it);
+// a value outside the range -- or a NaN / inf, which must reach the plane as such -- raises a flag, and the item's sum
+// plane is then cleared and redone with ds_add_f64 (the count plane is not touched again).  U(0, 1) values: ~1.5 % of the
+// items redo.  Round 3 tried this form on the old walk and saw nothing (the walk's own instructions bound it then).
 template <unsigned MASK>
 __global__ void __launch_bounds__(kThreads)
 k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ records,
                 const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
     extern __shared__ double lds_win[];
+    __shared__ int s_ehi, s_redo;
     if (blockIdx.x >= *n_items) return;
     const BinItem it = items[blockIdx.x];
     const int cells = t.lw * t.lh;                           // even (checked on the host)
     double* t_s = lds_win;
+    unsigned long long* t_q = reinterpret_cast<unsigned long long*>(lds_win);
     unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
     const uint4* rec = records + it.first;
-    uint4 cur = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+    const uint4 first = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+    if (threadIdx.x == 0) { s_ehi = 0; s_redo = 0; }
     for (int i = threadIdx.x; i < cells; i += kThreads) {
-        if (MASK & 1) t_s[i] = 0.0;
+        if (MASK & 1) t_q[i] = 0ull;
         if (MASK & 2) t_c[i] = 0u;
     }
     __syncthreads();
-    for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
-        const unsigned jn = j0 + kThreads + threadIdx.x;
-        const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
-        const bool valid = cur.x != b16::kNullCell;
-        int li = (int)(cur.x & 0xFFFFu);
-        const unsigned n = valid ? (cur.x >> 16) & 0xFFu : 0u;
-        unsigned r = cur.x >> 24;
-        const unsigned M2 = cur.z & 0xFFu, m2 = (cur.z >> 8) & 0xFFu;
-        const int stepA = (int)(signed char)((cur.z >> 16) & 0xFFu), stepAB = stepA + (int)(signed char)(cur.z >> 24);
-        const double dv = (double)__uint_as_float(cur.y);
-        for (unsigned j = 0; __any(j < n); ++j) {
-            if (j < n) {
-                if (MASK & 1) unsafeAtomicAdd(&t_s[li], dv);
-                if (MASK & 2) atomicAdd(&t_c[li], 1u);
-            }
-            r += m2;
-            const bool c = r >= M2;
-            r -= c ? M2 : 0u;
-            li += c ? stepAB : stepA;
+    int e_lo = 0;
+    if (MASK & 1) {
+        int e = 0;
+        if (first.x != b16::kNullCell) {
+            e = (int)((first.y >> 23) & 0xFFu);
+            if (e == 255) e = 0;                             // NaN / inf: found again (and flagged) by the walk
         }
-        cur = nxt;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e = max(e, __shfl_xor(e, off, 64));
+        if ((threadIdx.x & 63) == 0 && e > 0) atomicMax(&s_ehi, e);
+        __syncthreads();
+        e_lo = s_ehi + 3 - 22;                               // accepted exponents: [e_lo, e_lo + 22], normal numbers only
     }
+    // pass 0: count plane + fixed-point sums; pass 1 (only after a value did not fit): the sum plane again, as doubles
+    auto walk = [&](auto pass_c) {
+        constexpr int PASS = decltype(pass_c)::value;
+        uint4 cur = first;
+        for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
+            const unsigned jn = j0 + kThreads + threadIdx.x;
+            const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+            const bool valid = cur.x != b16::kNullCell;
+            int li = (int)(cur.x & 0xFFFFu);
+            const unsigned n = valid ? (cur.x >> 16) & 0xFFu : 0u;
+            unsigned r = cur.x >> 24;
+            const unsigned M2 = cur.z & 0xFFu, m2 = (cur.z >> 8) & 0xFFu;
+            const int stepA = (int)(signed char)((cur.z >> 16) & 0xFFu), stepAB = stepA + (int)(signed char)(cur.z >> 24);
+            const double dv = (double)__uint_as_float(cur.y);
+            unsigned long long q = 0ull;
+            if ((MASK & 1) && PASS == 0) {
+                const int e = (int)((cur.y >> 23) & 0xFFu);
+                const unsigned mant = cur.y & 0x7FFFFFu;
+                const bool zero = e == 0 && mant == 0u;
+                const bool fits = zero || (e != 255 && e >= max(e_lo, 1) && e <= e_lo + 22);
+                if (n > 0 && !fits) s_redo = 1;              // (benign race: every writer stores 1)
+                const long long mag = zero || !fits ? 0ll : (long long)(mant | 0x800000u) << (e - e_lo);
+                q = (unsigned long long)((cur.y >> 31) ? -mag : mag);
+            }
+            for (unsigned j = 0; __any(j < n); ++j) {
+                if (j < n) {
+                    if (MASK & 1) {
+                        if (PASS == 0) atomicAdd(&t_q[li], q);
+                        else unsafeAtomicAdd(&t_s[li], dv);
+                    }
+                    if ((MASK & 2) && PASS == 0) atomicAdd(&t_c[li], 1u);
+                }
+                r += m2;
+                const bool c = r >= M2;
+                r -= c ? M2 : 0u;
+                li += c ? stepAB : stepA;
+            }
+            cur = nxt;
+        }
+    };
+    walk(std::integral_constant<int, 0>{});
     __syncthreads();
+    if ((MASK & 1) && s_redo != 0) {
+        for (int i = threadIdx.x; i < cells; i += kThreads) t_s[i] = 0.0;
+        __syncthreads();
+        walk(std::integral_constant<int, 1>{});
+        __syncthreads();
+    }
+    const bool fixed = (MASK & 1) && s_redo == 0;
+    const double scale = fixed ? ldexp(1.0, e_lo - 150) : 1.0;
     const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
     const int x0 = bx * t.bins.tile_w - t.apron, y0 = t.bins.row0 + by * t.bins.tile_h - t.apron;      // window origin; rows relative to the state window
     for (int i = threadIdx.x; i < cells; i += kThreads) {
-        double s = (MASK & 1) ? t_s[i] : 0.0;
+        double s = 0.0;
+        if (MASK & 1) s = fixed ? (double)(long long)t_q[i] * scale : t_s[i];
         unsigned c = (MASK & 2) ? t_c[i] : 0u;
         if (s == 0.0 && c == 0u) continue;
         int ly = i / t.lw, lx = i - ly * t.lw;
