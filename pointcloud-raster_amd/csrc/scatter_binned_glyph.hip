@@ -365,24 +365,36 @@ struct LineStateMaker {
 // multiple q < 2^46 of 2^(E_lo - 150), and 65 536 of them (the most an item holds) sum without overflow in 63 bits: the
 // sum is EXACT, rounded once when it is merged (the f64 plane rounds every add).  E_lo is guessed from the item's first
 // 1024 values (their largest exponent + 3 at the top of the range: room for values 8 x larger, and down to 2^-19 of it);
-// a value outside the range -- or a NaN / inf, which must reach the plane as such -- raises a flag, and the item's sum
-// plane is then cleared and redone with ds_add_f64 (the count plane is not touched again).  U(0, 1) values: ~1.5 % of the
-// items redo.  Round 3 tried this form on the old walk and saw nothing (the walk's own instructions bound it then).
+// a value outside the range -- or a NaN / inf, which must reach the plane as such -- is left out of the fixed-point sums and
+// raises a flag; the item then converts its plane to doubles in place (one rounding to 53 bits) and walks the left-out
+// segments again with ds_add_f64 (the count plane is not touched again).  U(0, 1) values: ~1.5 % of the items have such a
+// segment; redoing the whole item instead cost the kernel 0.1 ms (an item that starts among the last ones and runs 2.6 x as
+// long IS the kernel's tail).  Round 3 tried the fixed-point form on the old walk and saw nothing (the walk's own
+// instructions bound it then).
+// LDS layout of k_tile_line_rec, fixed so that both planes are reached with an immediate DS offset from ONE packed register:
+//   [0, kLineCountBase)            static words
+//   [kLineCountBase, ...)          count plane, u32 per cell          (cells <= kLineMaxCells)
+//   [kLineSumBase, ...)            sum plane, 8 bytes per cell        (65 528: the largest 8-byte aligned DS offset)
+constexpr int kLineCountBase = 16, kLineSumBase = 65528, kLineMaxCells = 12288;
+static_assert((size_t)kLineSumBase + (size_t)kLineMaxCells * 8 <= 160 * 1024, "the Line window must fit the CU's LDS");
+
 template <unsigned MASK>
 __global__ void __launch_bounds__(kThreads)
 k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ records,
                 const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
-    extern __shared__ double lds_win[];
-    __shared__ int s_ehi, s_redo;
+    extern __shared__ double lds_win[];                      // (the whole segment is dynamic: no static LDS in this kernel)
     if (blockIdx.x >= *n_items) return;
     const BinItem it = items[blockIdx.x];
-    const int cells = t.lw * t.lh;                           // even (checked on the host)
-    double* t_s = lds_win;
-    unsigned long long* t_q = reinterpret_cast<unsigned long long*>(lds_win);
-    unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
+    const int cells = t.lw * t.lh;                           // <= kLineMaxCells (checked on the host)
+    char* lds = reinterpret_cast<char*>(lds_win);
+    int* s_ehi = reinterpret_cast<int*>(lds);
+    int* s_redo = s_ehi + 1;
+    unsigned* t_c = reinterpret_cast<unsigned*>(lds + kLineCountBase);
+    unsigned long long* t_q = reinterpret_cast<unsigned long long*>(lds + kLineSumBase);
+    double* t_s = reinterpret_cast<double*>(lds + kLineSumBase);
     const uint4* rec = records + it.first;
     const uint4 first = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
-    if (threadIdx.x == 0) { s_ehi = 0; s_redo = 0; }
+    if (threadIdx.x == 0) { *s_ehi = 0; *s_redo = 0; }
     for (int i = threadIdx.x; i < cells; i += kThreads) {
         if (MASK & 1) t_q[i] = 0ull;
         if (MASK & 2) t_c[i] = 0u;
@@ -397,60 +409,89 @@ k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ 
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) e = max(e, __shfl_xor(e, off, 64));
-        if ((threadIdx.x & 63) == 0 && e > 0) atomicMax(&s_ehi, e);
+        if ((threadIdx.x & 63) == 0 && e > 0) atomicMax(s_ehi, e);
         __syncthreads();
-        e_lo = s_ehi + 3 - 22;                               // accepted exponents: [e_lo, e_lo + 22], normal numbers only
+        e_lo = *s_ehi + 3 - 22;                              // accepted exponents: [e_lo, e_lo + 22], normal numbers only
     }
-    // pass 0: count plane + fixed-point sums; pass 1 (only after a value did not fit): the sum plane again, as doubles
+    // The walk's whole state in ONE register: st = (byte offset of the cell in the count plane) << 16 | remainder.
+    //   minor step taken  <=>  remainder >= 2M - 2m;   st += taken ? d1 : d0
+    //   d0 = (4 major) << 16 | 2m        d1 = (4 (major + minor)) << 16 + 2m - 2M        (plain 32-bit adds: no field borrows)
+    // Both plane addresses are shifts of st (the remainder stays below 2^15, so bit 15 -- bit 0 of st >> 15 -- is clear).
+    // Up to the shortest segment of the wave no lane needs masking; the steps there are unrolled by four.
+    // pass 0: count plane + fixed-point sums of the values that fit; pass 1 (only when some did not): those, as doubles
     auto walk = [&](auto pass_c) {
         constexpr int PASS = decltype(pass_c)::value;
         uint4 cur = first;
         for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
             const unsigned jn = j0 + kThreads + threadIdx.x;
             const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
-            const bool valid = cur.x != b16::kNullCell;
-            int li = (int)(cur.x & 0xFFFFu);
+            bool valid = cur.x != b16::kNullCell;
+            bool fits = true;
+            if (MASK & 1) {
+                const int e = (int)((cur.y >> 23) & 0xFFu);
+                fits = (cur.y & 0x7FFFFFFFu) == 0u || (e != 255 && e >= max(e_lo, 1) && e <= e_lo + 22);
+            }
+            if (PASS == 1) valid = valid && !fits;           // the second pass walks only what the first left out
             const unsigned n = valid ? (cur.x >> 16) & 0xFFu : 0u;
-            unsigned r = cur.x >> 24;
             const unsigned M2 = cur.z & 0xFFu, m2 = (cur.z >> 8) & 0xFFu;
-            const int stepA = (int)(signed char)((cur.z >> 16) & 0xFFu), stepAB = stepA + (int)(signed char)(cur.z >> 24);
+            const int sA4 = 4 * (int)(signed char)((cur.z >> 16) & 0xFFu), sB4 = 4 * (int)(signed char)(cur.z >> 24);
+            unsigned st = ((cur.x & 0xFFFFu) << 18) | (cur.x >> 24);
+            const unsigned thr = M2 - m2;
+            const unsigned d0 = ((unsigned)sA4 << 16) + m2, d1 = ((unsigned)(sA4 + sB4) << 16) + m2 - M2;
             const double dv = (double)__uint_as_float(cur.y);
             unsigned long long q = 0ull;
             if ((MASK & 1) && PASS == 0) {
                 const int e = (int)((cur.y >> 23) & 0xFFu);
-                const unsigned mant = cur.y & 0x7FFFFFu;
-                const bool zero = e == 0 && mant == 0u;
-                const bool fits = zero || (e != 255 && e >= max(e_lo, 1) && e <= e_lo + 22);
-                if (n > 0 && !fits) s_redo = 1;              // (benign race: every writer stores 1)
-                const long long mag = zero || !fits ? 0ll : (long long)(mant | 0x800000u) << (e - e_lo);
+                const bool zero = (cur.y & 0x7FFFFFFFu) == 0u;
+                if (n > 0 && !fits) *s_redo = 1;             // (benign race: every writer stores 1)
+                const long long mag = zero || !fits ? 0ll : (long long)((cur.y & 0x7FFFFFu) | 0x800000u) << (e - e_lo);
                 q = (unsigned long long)((cur.y >> 31) ? -mag : mag);
             }
-            for (unsigned j = 0; __any(j < n); ++j) {
-                if (j < n) {
-                    if (MASK & 1) {
-                        if (PASS == 0) atomicAdd(&t_q[li], q);
-                        else unsafeAtomicAdd(&t_s[li], dv);
-                    }
-                    if ((MASK & 2) && PASS == 0) atomicAdd(&t_c[li], 1u);
+            auto step = [&]() {
+                if (MASK & 1) {
+                    char* ps = lds + kLineSumBase + (st >> 15);
+                    if (PASS == 0) atomicAdd(reinterpret_cast<unsigned long long*>(ps), q);
+                    else unsafeAtomicAdd(reinterpret_cast<double*>(ps), dv);
                 }
-                r += m2;
-                const bool c = r >= M2;
-                r -= c ? M2 : 0u;
-                li += c ? stepAB : stepA;
+                if ((MASK & 2) && PASS == 0) atomicAdd(reinterpret_cast<unsigned*>(lds + kLineCountBase + (st >> 16)), 1u);
+            };
+            auto advance = [&]() { st += (st & 0xFFFFu) >= thr ? d1 : d0; };
+            // the shortest and the longest walk of the wave (null records: none / 0)
+            unsigned nmin = valid ? n : 0xFFFFu, nmax = n;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                nmin = min(nmin, (unsigned)__shfl_xor((int)nmin, off, 64));
+                nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, off, 64));
+            }
+            nmin = __builtin_amdgcn_readfirstlane(nmin);
+            nmax = __builtin_amdgcn_readfirstlane(nmax);
+            if (nmin > nmax) nmin = 0;                        // (a wave of null records)
+            unsigned j = 0;
+            if (valid) {
+                for (; j + 4 <= nmin; j += 4) {
+                    step(); advance(); step(); advance(); step(); advance(); step(); advance();
+                }
+                for (; j < nmin; ++j) { step(); advance(); }
+            }
+            j = nmin;
+            for (; j < nmax; ++j) {
+                if (j < n) step();
+                advance();
             }
             cur = nxt;
         }
     };
     walk(std::integral_constant<int, 0>{});
     __syncthreads();
-    if ((MASK & 1) && s_redo != 0) {
-        for (int i = threadIdx.x; i < cells; i += kThreads) t_s[i] = 0.0;
+    const double scale = ldexp(1.0, e_lo - 150);
+    const bool redo = (MASK & 1) && *s_redo != 0;
+    if (redo) {
+        for (int i = threadIdx.x; i < cells; i += kThreads) t_s[i] = (double)(long long)t_q[i] * scale;
         __syncthreads();
         walk(std::integral_constant<int, 1>{});
         __syncthreads();
     }
-    const bool fixed = (MASK & 1) && s_redo == 0;
-    const double scale = fixed ? ldexp(1.0, e_lo - 150) : 1.0;
+    const bool fixed = (MASK & 1) && !redo;
     const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
     const int x0 = bx * t.bins.tile_w - t.apron, y0 = t.bins.row0 + by * t.bins.tile_h - t.apron;      // window origin; rows relative to the state window
     for (int i = threadIdx.x; i < cells; i += kThreads) {
@@ -525,6 +566,12 @@ bool glyph_tile(const pcr_hip_engine* e, const GlyphDev& gl, unsigned mask, Glyp
     const int side = ((int)std::floor(std::sqrt((double)limit))) & ~1;
     const int need = apron_needed(g, gl);
     int S = std::min(128, (side - 2 * need) & ~7);
+    if (gl.type == PCR_HIP_GLYPH_LINE && !gl.half_length) {
+        // the walk-state tile kernel (k_tile_line_rec) wants the whole window within kLineMaxCells cells whatever the planes:
+        // one tile shape for Sum, Count and WeightedAverage
+        const int side_rec = ((int)std::floor(std::sqrt((double)kLineMaxCells))) & ~1;           // 110
+        if (side_rec - 2 * need >= 32) S = std::min(S, (side_rec - 2 * need) & ~7);
+    }
     if (S < 32) S = 32;
     auto bands_for = [&](int s) {
         const int br = band_rows_for(g, s, s, e->max_bins);
@@ -644,7 +691,7 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
         PCR_HIP_TRY(hipMemsetAsync(e->d_scratch + L.o_fbc, 0, 4, e->stream));
         const bool covered = t.apron >= t.need && !gl.half_length;
         // walk-state records: every kept cell lies inside the window, the window's pitch fits an int8 step
-        const bool state_records = covered && t.lw <= 127 && (t.lw * t.lh) % 2 == 0 && t.lw * t.lh <= 65536;
+        const bool state_records = covered && t.lw <= 127 && t.lw * t.lh <= kLineMaxCells;
         for (int row0 = 0; row0 < e->gd.st_rows; row0 += band16) {
             const int rows = std::min(band16, e->gd.st_rows - row0);
             GridDev gd = e->gd;
@@ -663,8 +710,9 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
             if (rc) return rc;
             ScopedKernelTimer tm(e, "k_tile_line");
             auto go = [&](auto kernel) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, e->gd, t, pl, bb.records, bb.items, bb.n_items);
+                const size_t bytes = state_records ? (size_t)kLineSumBase + ((mask & 1) ? (size_t)t.lw * t.lh * 8 : 0) : lds;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+                hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), bytes, e->stream, e->gd, t, pl, bb.records, bb.items, bb.n_items);
             };
 #define PCR_LINE16(M) if (state_records) go(&k_tile_line_rec<M>); else if (covered) go(&k_tile_line16<M, true>); else go(&k_tile_line16<M, false>);
             switch (mask) {
