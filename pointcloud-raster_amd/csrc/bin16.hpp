@@ -110,8 +110,8 @@ k_b16_count(GridDev g, BinGeom b, int cb, const double* __restrict__ x, const do
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (p0 + u * kCountThreads >= pairs) break;              // uniform
-                    xs[u] = x2[p0 + u * kCountThreads];
-                    ys[u] = y2[p0 + u * kCountThreads];
+                    xs[u] = stream_load(x2 + p0 + u * kCountThreads);
+                    ys[u] = stream_load(y2 + p0 + u * kCountThreads);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

@@ -92,8 +92,8 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
             double2 xs[4], ys[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                xs[u] = x2[p0 + u * kCountThreads];
-                ys[u] = y2[p0 + u * kCountThreads];
+                xs[u] = stream_load(x2 + p0 + u * kCountThreads);
+                ys[u] = stream_load(y2 + p0 + u * kCountThreads);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -240,7 +240,7 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
         const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
         for (int q = 0; q < PER_THREAD / 4; ++q) {
-            uint4 kk = k4[q * THREADS + threadIdx.x];
+            uint4 kk = stream_load(k4 + q * THREADS + threadIdx.x);
             key[4 * q + 0] = kk.x; key[4 * q + 1] = kk.y; key[4 * q + 2] = kk.z; key[4 * q + 3] = kk.w;
         }
     } else {
@@ -290,7 +290,7 @@ bin_scatter_chunk(unsigned char* lds_raw, const BinGeom& b, uint64_t base, const
                 unsigned i0 = (unsigned)base + 4u * p;
                 val[4 * q + 0] = i0; val[4 * q + 1] = i0 + 1; val[4 * q + 2] = i0 + 2; val[4 * q + 3] = i0 + 3;
             } else {
-                uint4 vv = v ? v4[p] : make_uint4(0u, 0u, 0u, 0u);
+                uint4 vv = v ? stream_load(v4 + p) : make_uint4(0u, 0u, 0u, 0u);
                 val[4 * q + 0] = vv.x; val[4 * q + 1] = vv.y; val[4 * q + 2] = vv.z; val[4 * q + 3] = vv.w;
             }
         }
@@ -552,7 +552,7 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const unsigned j = j0 + u * kThreads;
-            r[u] = j < it.count ? rec[j] : make_uint2(0xFFFFFFFFu, 0u);
+            r[u] = j < it.count ? stream_load(rec + j) : make_uint2(0xFFFFFFFFu, 0u);
         }
     };
     fetch(cur, threadIdx.x);

@@ -213,7 +213,7 @@ k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ re
     unsigned* t_c = reinterpret_cast<unsigned*>(t_s + ((MASK & 1) ? cells : 0));
     // the first records are in flight while the window is cleared
     const uint4* rec = records + it.first;
-    uint4 cur = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+    uint4 cur = threadIdx.x < it.count ? stream_load(rec + threadIdx.x) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
     for (int i = threadIdx.x; i < cells; i += kThreads) {
         if (MASK & 1) t_s[i] = 0.0;
         if (MASK & 2) t_c[i] = 0u;
@@ -226,7 +226,7 @@ k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ re
     // every wave runs the same number of rounds (the walk below is wave-cooperative: shuffles inside)
     for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
         const unsigned jn = j0 + kThreads + threadIdx.x;
-        const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+        const uint4 nxt = jn < it.count ? stream_load(rec + jn) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
         const bool valid = cur.x != b16::kNullCell;
         LineParams q{};
         if (valid) {
@@ -393,7 +393,7 @@ k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ 
     unsigned long long* t_q = reinterpret_cast<unsigned long long*>(lds + kLineSumBase);
     double* t_s = reinterpret_cast<double*>(lds + kLineSumBase);
     const uint4* rec = records + it.first;
-    const uint4 first = threadIdx.x < it.count ? rec[threadIdx.x] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+    const uint4 first = threadIdx.x < it.count ? stream_load(rec + threadIdx.x) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
     if (threadIdx.x == 0) { *s_ehi = 0; *s_redo = 0; }
     for (int i = threadIdx.x; i < cells; i += kThreads) {
         if (MASK & 1) t_q[i] = 0ull;
@@ -424,7 +424,7 @@ k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ 
         uint4 cur = first;
         for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
             const unsigned jn = j0 + kThreads + threadIdx.x;
-            const uint4 nxt = jn < it.count ? rec[jn] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+            const uint4 nxt = jn < it.count ? stream_load(rec + jn) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
             bool valid = cur.x != b16::kNullCell;
             bool fits = true;
             if (MASK & 1) {

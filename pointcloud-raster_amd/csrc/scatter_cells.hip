@@ -166,7 +166,7 @@ k_cell_gauss(GridDev g, BinGeom b, CellGauss P, PlanesDev pl, const uint4* __res
 #pragma unroll
     for (int k = 0; k < kRecPerThread; ++k) {
         const unsigned j = threadIdx.x + k * kTileThreads;
-        rc[k] = j < it.count ? rec[j] : make_uint4(kNullCell, 0u, 0u, 0u);
+        rc[k] = j < it.count ? stream_load(rec + j) : make_uint4(kNullCell, 0u, 0u, 0u);
         // a record is only ever trusted as far as the tile goes: a local cell outside it (a record written for another tile
         // geometry, a slot the scatter pass never filled) is dropped here instead of indexing the LDS arrays below
         if (rc[k].x >= (unsigned)cells) rc[k].x = kNullCell;

@@ -105,7 +105,7 @@ k_tile_moments(GridDev g, BinGeom b, float inv2sx2, float inv2sy2, const uint4* 
 #pragma unroll
         for (int k = 0; k < kRecs; ++k) {
             const unsigned j = threadIdx.x + k * kMomThreads;
-            rc[k] = j < cn ? rec[j] : make_uint4(b16::kNullCell, 0u, 0u, 0u);
+            rc[k] = j < cn ? stream_load(rec + j) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
         }
         for (int i = threadIdx.x; i <= kCells; i += kMomThreads) off[i] = 0;
         __syncthreads();

@@ -153,10 +153,10 @@ k_finalize_group(GridDev g, PlanesDev pl, unsigned need, const uint32_t* __restr
         bool live[VEC];
         if (VEC == 4) {
             float4 t;
-            if (need & 1) { t = *reinterpret_cast<const float4*>(pl.sum + si); s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w; }
-            if (need & 2) { t = *reinterpret_cast<const float4*>(pl.wgt + si); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
-            if (need & 4) { t = *reinterpret_cast<const float4*>(pl.mx + si); mx[0] = t.x; mx[1] = t.y; mx[2] = t.z; mx[3] = t.w; }
-            if (need & 8) { t = *reinterpret_cast<const float4*>(pl.mn + si); mn[0] = t.x; mn[1] = t.y; mn[2] = t.z; mn[3] = t.w; }
+            if (need & 1) { t = stream_load(reinterpret_cast<const float4*>(pl.sum + si)); s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w; }
+            if (need & 2) { t = stream_load(reinterpret_cast<const float4*>(pl.wgt + si)); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
+            if (need & 4) { t = stream_load(reinterpret_cast<const float4*>(pl.mx + si)); mx[0] = t.x; mx[1] = t.y; mx[2] = t.z; mx[3] = t.w; }
+            if (need & 8) { t = stream_load(reinterpret_cast<const float4*>(pl.mn + si)); mn[0] = t.x; mn[1] = t.y; mn[2] = t.z; mn[3] = t.w; }
         } else {
             if (need & 1) s[0] = pl.sum[si];
             if (need & 2) w[0] = pl.wgt[si];
