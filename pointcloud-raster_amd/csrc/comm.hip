@@ -19,8 +19,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -80,6 +83,32 @@ Rccl* rccl() {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) { r.error = std::string("RCCL not found: ") + dlerror(); return; }
+        // TWO copies of RCCL in one process (a host application that loaded ROCm's librccl before it imported torch, whose
+        // wheel bundles its own) each bring their rocm_smi / roctx statics: round 3 saw `double free or corruption` at
+        // process exit.  The mapping table says whether that is the case; refuse to add communicators on top of it.
+        {
+            std::set<std::string> copies;
+            if (FILE* maps = std::fopen("/proc/self/maps", "r")) {
+                char line[1024];
+                while (std::fgets(line, sizeof line, maps)) {
+                    const char* path = std::strchr(line, '/');
+                    if (!path) continue;
+                    const char* leaf = std::strrchr(path, '/');
+                    if (leaf && std::strncmp(leaf + 1, "librccl", 7) == 0) {
+                        std::string full(path);
+                        while (!full.empty() && (full.back() == '\n' || full.back() == ' ')) full.pop_back();
+                        copies.insert(full);
+                    }
+                }
+                std::fclose(maps);
+            }
+            if (copies.size() > 1) {
+                r.error = "two copies of RCCL are mapped into this process (";
+                for (const auto& c : copies) r.error += c + "; ";
+                r.error += "): load one RCCL only -- e.g. import torch before anything that loads ROCm's librccl, or set PCR_HIP_RCCL";
+                return;
+            }
+        }
         auto sym = [&](const char* n) -> void* {
             void* p = dlsym(r.lib, n);
             if (!p && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + n;

@@ -146,3 +146,36 @@ def test_argument_checks():
     assert L.pcr_hip_comm_halo_plan(None, 2, 0, *[C.byref(x) for x in v]) == 1
     word = C.c_int32(3)
     assert L.pcr_hip_comm_agree_max_i32(None, C.byref(word), None) == 1
+
+
+def test_two_copies_of_rccl_in_one_process_are_refused(tmp_path):
+    """Round 3 ended a test process with `double free or corruption` because a second RCCL (ROCm's) had been loaded beside
+    torch's bundled one (each brings its own rocm_smi / roctx statics).  The library now looks at the process's mapping
+    table before it resolves RCCL: two copies -> pcr_hip_comm_available() == 0 and every comm entry point says why.
+    Run in a child process that leaves with os._exit (the two copies must not run their exit handlers)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    a = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    b = "/opt/rocm/lib/librccl.so.1"
+    if not (os.path.exists(a) and os.path.exists(b)) or os.path.realpath(a) == os.path.realpath(b):
+        pytest.skip("needs torch's bundled RCCL and ROCm's as two different files")
+    A = load_cabi()
+    code = f"""
+import ctypes, os, sys
+ctypes.CDLL({a!r}, mode=ctypes.RTLD_GLOBAL)
+ctypes.CDLL({b!r}, mode=ctypes.RTLD_GLOBAL)
+L = ctypes.CDLL({A.LIB_PATH!r})
+L.pcr_hip_last_error.restype = ctypes.c_char_p
+ok = L.pcr_hip_comm_available()
+buf = (ctypes.c_uint8 * 128)()
+rc = L.pcr_hip_comm_unique_id(buf)
+sys.stdout.write(f"{{ok}} {{rc}} {{L.pcr_hip_last_error().decode()}}\\n")
+sys.stdout.flush()
+os._exit(0)
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ok, rc, msg = out.stdout.strip().split(" ", 2)
+    assert ok == "0" and rc != "0" and "two copies of RCCL" in msg, out.stdout
