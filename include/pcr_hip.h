@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PCR_HIP_ABI_VERSION 2
+#define PCR_HIP_ABI_VERSION 3   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2 */
 
 typedef enum pcr_hip_status {
     PCR_HIP_OK = 0,
