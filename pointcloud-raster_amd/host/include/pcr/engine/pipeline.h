@@ -43,6 +43,11 @@ struct PipelineConfig {
 
     ExecutionMode exec_mode = ExecutionMode::Auto;   // GPU, Auto and Hybrid all run the HIP engine
 
+    // A grid whose accumulation state (4 B per cell and plane, + the finalized bands) exceeds gpu_memory_budget (0 = ~80 %
+    // of the free GPU memory) is processed OUT OF CORE: in row bands of whole reference-tile rows, one band's state in HBM at
+    // a time, the others in host memory up to host_cache_budget (0 = ~50 % of the free host memory), beyond that in files
+    // under state_dir (a temporary directory when empty) -- the role of the reference's TileManager LRU + disk spill
+    // (src/engine/tile_manager.cpp:76-375).
     size_t gpu_memory_budget = 0;
     size_t host_cache_budget = 0;
     size_t chunk_size = 0;
@@ -144,10 +149,15 @@ public:
     struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; int scatter_chunk; };
     ScatterInfo last_scatter() const;
 
+    /// True when the grid's state did not fit the device budget and the pipeline sweeps it in row bands (out of core).
+    bool out_of_core() const;
+
 private:
     Pipeline() = default;
     struct Impl;
+    struct Banded;                       // out-of-core driver: row bands of whole reference-tile rows, one in HBM at a time
     std::unique_ptr<Impl> impl_;
+    std::unique_ptr<Banded> banded_;
 };
 
 // Why the last Pipeline::create() on this thread returned nullptr.

@@ -28,6 +28,8 @@
 #include <set>
 #include <vector>
 
+#include <unistd.h>
+
 namespace pcr {
 
 namespace {
@@ -720,6 +722,54 @@ struct Pipeline::Impl {
         return detail::hip_status(pcr_hip_stream_synchronize(stream));
     }
 
+    // The state WINDOW of this pipeline (any shard) as host copies: planes[4 g + p] (state_rows x W floats; empty when group g
+    // has no plane p) + the touched flags.  What the out-of-core driver parks between two visits of a band.
+    Status export_window(std::vector<std::vector<float>>& planes, std::vector<uint32_t>& touched) {
+        DeviceScope dev(cfg.cuda_device_id);
+        Status s = define_all_planes();
+        if (!s.ok()) return s;
+        const size_t cells = (size_t)hg.state_rows * hg.width;
+        planes.assign(groups.size() * 4, {});
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (int p = 0; p < 4; ++p) {
+                if (!(groups[gi].mask & kPlaneBits[p])) continue;
+                planes[gi * 4 + p].resize(cells);
+                s = detail::hip_status(pcr_hip_memcpy_d2h(planes[gi * 4 + p].data(), groups[gi].planes[p].data(), cells * sizeof(float), stream));
+                if (!s.ok()) return s;
+            }
+        uint32_t* d_touched = nullptr;
+        int tx = 0, ty = 0;
+        if (!(s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, &tx, &ty))).ok()) return s;
+        touched.resize((size_t)tx * ty);
+        if (!(s = detail::hip_status(pcr_hip_memcpy_d2h(touched.data(), d_touched, touched.size() * 4, stream))).ok()) return s;
+        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    }
+    Status import_window(const std::vector<std::vector<float>>& planes, const std::vector<uint32_t>& touched) {
+        DeviceScope dev(cfg.cuda_device_id);
+        const size_t cells = (size_t)hg.state_rows * hg.width;
+        if (planes.size() != groups.size() * 4)
+            return Status::error(StatusCode::InvalidArgument, "pipeline: parked state does not match the pipeline's groups");
+        Status s = Status::success();
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            for (int p = 0; p < 4; ++p) {
+                if (!(groups[gi].mask & kPlaneBits[p])) continue;
+                if (planes[gi * 4 + p].size() != cells)
+                    return Status::error(StatusCode::InvalidArgument, "pipeline: parked state does not match the band's window");
+                s = detail::hip_status(pcr_hip_memcpy_h2d(groups[gi].planes[p].data(), planes[gi * 4 + p].data(), cells * sizeof(float), stream));
+                if (!s.ok()) return s;
+            }
+            groups[gi].defined = true;
+            groups[gi].fresh = false;
+        }
+        uint32_t* d_touched = nullptr;
+        int tx = 0, ty = 0;
+        if (!(s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, &tx, &ty))).ok()) return s;
+        if (touched.size() != (size_t)tx * ty)
+            return Status::error(StatusCode::InvalidArgument, "pipeline: parked touched flags do not match the tile grid");
+        if (!(s = detail::hip_status(pcr_hip_memcpy_h2d(d_touched, touched.data(), touched.size() * 4, stream))).ok()) return s;
+        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    }
+
     Status save_state(const std::string& dir_in) {
         std::string dir;
         Status s = checkpoint_dir(dir_in, &dir);
@@ -843,25 +893,299 @@ struct Pipeline::Impl {
     }
 };
 
+
+
+// ---- out-of-core grids: row bands of whole reference-tile rows ---------------------------------------------------
+// The reference keeps every tile's state behind a TileManager: an LRU cache in memory, evicted tiles flushed to `.pcrt`
+// files and loaded back on the next acquire (src/engine/tile_manager.cpp:76-138, 183-375), so that a grid may be larger
+// than memory.  This build keeps the state of the WHOLE grid in HBM -- until it does not fit the budget.
+// Then the grid is swept in bands of whole reference-tile rows: footprints are clipped to the reference tile of their
+// centre cell (Q4), so nothing a band's points paint can land outside the band -- a band is an ordinary row-block shard
+// with no halo to exchange.  One band's planes are in HBM at a time (a sub-pipeline created for the visit); the others are
+// parked as host copies up to host_cache_budget and, least recently used first, in files under state_dir beyond it.  Every
+// ingest visits every band (the kernels keep the points whose centre row the band owns); finalize visits them once more
+// and assembles the host result.  Results are those of the in-core pipeline bit for bit: the same kernels run on the same
+// points of each tile, in the same order.
+struct Pipeline::Banded {
+    PipelineConfig cfg;                                   // the WHOLE grid, as the caller gave it
+    std::vector<std::pair<int, int>> bands;               // [r0, r1), multiples of the tile height
+    struct Parked {
+        bool any = false, on_disk = false;
+        std::vector<std::vector<float>> planes;
+        std::vector<uint32_t> touched;
+        size_t bytes = 0;
+        uint64_t stamp = 0;
+    };
+    std::vector<Parked> parked;
+    size_t host_budget = 0, host_used = 0, spills = 0, reloads = 0;
+    uint64_t clock = 0;
+    std::string spill_dir;
+    bool own_spill_dir = false;
+    std::unique_ptr<Grid> result;
+    bool finalized = false;
+    size_t collections = 0, points = 0, tiles_active = 0;
+    ProgressCallback callback;
+    ScatterInfo last{};
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+
+    ~Banded() {
+        if (own_spill_dir && !spill_dir.empty()) {
+            std::error_code ec;
+            std::filesystem::remove_all(spill_dir, ec);
+        }
+    }
+
+    // bytes of device memory one grid row costs: 4 B per cell and plane, + the finalized bands a sub-pipeline keeps
+    static size_t bytes_per_row(const PipelineConfig& c) {
+        struct G { std::string ch; GlyphSpec gl; uint32_t mask; };
+        std::vector<G> gs;
+        for (const auto& r : c.reductions) {
+            int gi = -1;
+            for (size_t k = 0; k < gs.size(); ++k)
+                if (gs[k].ch == r.value_channel && same_glyph(gs[k].gl, r.glyph)) gi = (int)k;
+            if (gi < 0) { gs.push_back({r.value_channel, r.glyph, 0u}); gi = (int)gs.size() - 1; }
+            gs[gi].mask |= planes_for(r.type);
+        }
+        size_t planes = 0;
+        for (const auto& g : gs)
+            for (int p = 0; p < 4; ++p) planes += (g.mask & kPlaneBits[p]) ? 1 : 0;
+        return (size_t)c.grid.width * 4 * (planes + c.reductions.size());
+    }
+
+    std::string spill_path(size_t b) const { return spill_dir + "/band_" + std::to_string(b) + ".state"; }
+
+    Status spill(size_t b) {
+        Parked& k = parked[b];
+        std::FILE* f = std::fopen(spill_path(b).c_str(), "wb");
+        if (!f) return Status::error(StatusCode::IoError, "pipeline: cannot write " + spill_path(b));
+        bool ok = true;
+        const uint64_t np = k.planes.size();
+        ok = ok && std::fwrite(&np, 8, 1, f) == 1;
+        for (const auto& pl : k.planes) {
+            const uint64_t n = pl.size();
+            ok = ok && std::fwrite(&n, 8, 1, f) == 1 && (n == 0 || std::fwrite(pl.data(), 4, n, f) == n);
+        }
+        const uint64_t nt = k.touched.size();
+        ok = ok && std::fwrite(&nt, 8, 1, f) == 1 && (nt == 0 || std::fwrite(k.touched.data(), 4, nt, f) == nt);
+        ok = (std::fclose(f) == 0) && ok;
+        if (!ok) return Status::error(StatusCode::IoError, "pipeline: short write to " + spill_path(b));
+        host_used -= k.bytes;
+        std::vector<std::vector<float>>().swap(k.planes);
+        std::vector<uint32_t>().swap(k.touched);
+        k.on_disk = true;
+        ++spills;
+        return Status::success();
+    }
+
+    Status reload(size_t b) {
+        Parked& k = parked[b];
+        std::FILE* f = std::fopen(spill_path(b).c_str(), "rb");
+        if (!f) return Status::error(StatusCode::IoError, "pipeline: cannot read " + spill_path(b));
+        bool ok = true;
+        uint64_t np = 0;
+        ok = ok && std::fread(&np, 8, 1, f) == 1 && np < 4096;
+        if (ok) k.planes.assign((size_t)np, {});
+        for (uint64_t i = 0; ok && i < np; ++i) {
+            uint64_t n = 0;
+            ok = std::fread(&n, 8, 1, f) == 1 && n * 4 <= k.bytes;
+            if (ok) { k.planes[i].resize((size_t)n); ok = n == 0 || std::fread(k.planes[i].data(), 4, n, f) == n; }
+        }
+        uint64_t nt = 0;
+        ok = ok && std::fread(&nt, 8, 1, f) == 1 && nt < (1u << 28);
+        if (ok) { k.touched.resize((size_t)nt); ok = nt == 0 || std::fread(k.touched.data(), 4, nt, f) == nt; }
+        std::fclose(f);
+        if (!ok) return Status::error(StatusCode::IoError, "pipeline: corrupt band state file " + spill_path(b));
+        k.on_disk = false;
+        host_used += k.bytes;
+        ++reloads;
+        return Status::success();
+    }
+
+    // park band b's state (already in k.planes / k.touched) and evict the least recently used bands beyond the host budget
+    Status account(size_t b) {
+        Parked& k = parked[b];
+        size_t bytes = k.touched.size() * 4;
+        for (const auto& pl : k.planes) bytes += pl.size() * 4;
+        host_used += bytes - (k.any && !k.on_disk ? k.bytes : 0);
+        k.bytes = bytes;
+        k.any = true;
+        k.on_disk = false;
+        k.stamp = ++clock;
+        while (host_used > host_budget) {
+            size_t victim = parked.size();
+            for (size_t i = 0; i < parked.size(); ++i)
+                if (parked[i].any && !parked[i].on_disk && (victim == parked.size() || parked[i].stamp < parked[victim].stamp)) victim = i;
+            if (victim == parked.size()) break;
+            Status s = spill(victim);
+            if (!s.ok()) return s;
+        }
+        return Status::success();
+    }
+
+    std::unique_ptr<Pipeline> visit(size_t b, Status* st) {
+        PipelineConfig c = cfg;
+        c.shard_row_begin = bands[b].first;
+        c.shard_row_end = bands[b].second;
+        c.result_location = MemoryLocation::Host;
+        c.output_path.clear();
+        c.state_dir.clear();
+        c.resume = false;
+        std::unique_ptr<Pipeline> sub = Pipeline::create(c);
+        if (!sub) { *st = Status::error(StatusCode::OutOfMemory, "pipeline: out-of-core band could not be created: " + pipeline_create_error()); return nullptr; }
+        Parked& k = parked[b];
+        if (k.any) {
+            if (k.on_disk && !(*st = reload(b)).ok()) return nullptr;
+            if (!(*st = sub->impl_->import_window(k.planes, k.touched)).ok()) return nullptr;
+            k.stamp = ++clock;
+        }
+        *st = Status::success();
+        return sub;
+    }
+
+    Status ingest(const PointCloud& cloud) {
+        if (cloud.count() == 0) return Status::success();
+        // one device copy of a host cloud for all bands (each band's kernels read every point and keep its own)
+        std::unique_ptr<PointCloud> staged;
+        const PointCloud* src = &cloud;
+        if (cloud.location() != MemoryLocation::Device) {
+            staged = cloud.to(MemoryLocation::Device);
+            if (staged) src = staged.get();
+        }
+        for (size_t b = 0; b < bands.size(); ++b) {
+            Status s = Status::success();
+            std::unique_ptr<Pipeline> sub = visit(b, &s);
+            if (!sub) return s;
+            if (!(s = sub->ingest(*src)).ok()) return s;
+            last = sub->last_scatter();
+            if (!parked[b].any && last.points_valid == 0) continue;        // nothing of this cloud (or any before) fell here
+            Parked& k = parked[b];
+            if (!(s = sub->impl_->export_window(k.planes, k.touched)).ok()) return s;
+            if (!(s = account(b)).ok()) return s;
+        }
+        ++collections;
+        points += cloud.count();
+        if (callback) {
+            ProgressInfo info = stats();
+            if (!callback(info)) return Status::error(StatusCode::InvalidArgument, "pipeline: cancelled by user");
+        }
+        return Status::success();
+    }
+
+    Status finalize() {
+        const GridConfig& g = cfg.grid;
+        std::vector<BandDesc> descs;
+        for (const auto& r : cfg.reductions) {
+            BandDesc d;
+            d.name = r.output_band_name.empty() ? r.value_channel + "_" + std::to_string(static_cast<int>(r.type)) : r.output_band_name;
+            d.dtype = DataType::Float32;
+            d.is_state = false;
+            descs.push_back(d);
+        }
+        if (descs.empty()) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
+        if (!result) result = Grid::create(g.width, g.height, descs, MemoryLocation::Host);
+        if (!result) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
+        tiles_active = 0;
+        for (size_t b = 0; b < bands.size(); ++b) {
+            Status s = Status::success();
+            std::unique_ptr<Pipeline> sub = visit(b, &s);
+            if (!sub) return s;
+            if (!(s = sub->finalize()).ok()) return s;
+            const Grid* part = sub->result();
+            const int rows = bands[b].second - bands[b].first;
+            if (!part || part->rows() != rows) return Status::error(StatusCode::CudaError, "pipeline: out-of-core band returned no result");
+            for (size_t o = 0; o < descs.size(); ++o)
+                std::copy_n(part->band_f32((int)o), (size_t)rows * g.width, result->band_f32((int)o) + (size_t)bands[b].first * g.width);
+            for (uint32_t t : parked[b].touched) tiles_active += t ? 1 : 0;
+        }
+        finalized = true;
+        if (!cfg.output_path.empty()) return write_geotiff(cfg.output_path, *result, cfg.grid, GeoTiffOptions());
+        return Status::success();
+    }
+
+    ProgressInfo stats() const {
+        ProgressInfo info;
+        info.collections_processed = collections;
+        info.points_processed = points;
+        info.tiles_active = tiles_active;
+        info.elapsed_seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+        return info;
+    }
+};
+
 Pipeline::~Pipeline() = default;
+
+bool Pipeline::out_of_core() const { return banded_ != nullptr; }
 
 std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
     auto p = std::unique_ptr<Pipeline>(new Pipeline());
+    auto fail_with = [](const Status& s) {
+        g_create_error = s.message;
+        std::fprintf(stderr, "Error: %s\n", s.message.c_str());    // loud: there is no fallback path
+        return std::unique_ptr<Pipeline>();
+    };
+    // Out of core?  Only whole-grid pipelines (a row-block shard is somebody's band already), only when the state of the
+    // whole grid exceeds the device budget.
+    const GridConfig& g = config.grid;
+    if (config.shard_row_begin < 0 && config.shard_row_end < 0 && config.exec_mode != ExecutionMode::CPU && g.width > 0 && g.height > 0 &&
+        g.tile_height > 0 && !config.reductions.empty() && cuda_device_available() && config.cuda_device_id >= 0 &&
+        config.cuda_device_id < cuda_device_count()) {
+        size_t budget = config.gpu_memory_budget;
+        if (budget == 0) {
+            size_t free_mem = 0, total_mem = 0;
+            if (cuda_get_memory_info(&free_mem, &total_mem, config.cuda_device_id)) budget = (size_t)(free_mem * 0.8);
+        }
+        const size_t per_row = Banded::bytes_per_row(config);
+        if (budget > 0 && per_row * (size_t)g.height > budget) {
+            for (const auto& r : config.reductions)
+                if (!registered(r.type)) return fail_with(Status::error(StatusCode::InvalidArgument, "pipeline: unknown reduction type"));
+            const int th = g.tile_height;
+            const size_t fit = budget / std::max<size_t>(per_row * (size_t)th, 1);          // whole tile rows that fit
+            const int band_rows = (int)std::min<size_t>(std::max<size_t>(fit, 1) * (size_t)th, (size_t)g.height + th);
+            if (config.result_location == MemoryLocation::Device)
+                return fail_with(Status::error(StatusCode::InvalidArgument,
+                    "pipeline: the grid's state (" + std::to_string(per_row * (size_t)g.height >> 20) + " MB) exceeds the device budget (" +
+                    std::to_string(budget >> 20) + " MB): it is processed out of core, which needs result_location = Host"));
+            p->banded_ = std::make_unique<Banded>();
+            Banded& bd = *p->banded_;
+            bd.cfg = config;
+            for (int r0 = 0; r0 < g.height; r0 += band_rows) bd.bands.push_back({r0, std::min(r0 + band_rows, g.height)});
+            bd.parked.resize(bd.bands.size());
+            bd.host_budget = config.host_cache_budget;
+            if (bd.host_budget == 0) {
+                long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+                bd.host_budget = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz / 2 : (size_t)8 << 30;
+            }
+            bd.spill_dir = config.state_dir;
+            if (bd.spill_dir.empty()) {
+                std::error_code ec;
+                bd.spill_dir = (std::filesystem::temp_directory_path(ec) / ("pcr_bands_" + std::to_string((long long)getpid()) + "_" +
+                                std::to_string((unsigned long long)(uintptr_t)p.get()))).string();
+                bd.own_spill_dir = true;
+            }
+            std::error_code ec;
+            std::filesystem::create_directories(bd.spill_dir, ec);
+            if (ec) return fail_with(Status::error(StatusCode::IoError, "pipeline: cannot create " + bd.spill_dir));
+            // the first band is created once here, so that an impossible configuration fails at create like an in-core one
+            Status s = Status::success();
+            std::unique_ptr<Pipeline> probe = bd.visit(0, &s);
+            if (!probe) return fail_with(s);
+            std::fprintf(stderr, "Info: grid state %zu MB exceeds the device budget %zu MB - out of core in %zu bands of %d rows\n",
+                         per_row * (size_t)g.height >> 20, budget >> 20, bd.bands.size(), band_rows);
+            g_create_error.clear();
+            return p;
+        }
+    }
     p->impl_ = std::make_unique<Impl>();
     p->impl_->cfg = config;
     Status s = p->impl_->init();
     if (s.ok() && config.resume && !config.state_dir.empty()) s = p->impl_->load_state(config.state_dir);
-    if (!s.ok()) {
-        g_create_error = s.message;
-        std::fprintf(stderr, "Error: %s\n", s.message.c_str());    // loud: there is no fallback path
-        return nullptr;
-    }
+    if (!s.ok()) return fail_with(s);
     g_create_error.clear();
     return p;
 }
 
 Status Pipeline::validate() const {
-    const PipelineConfig& c = impl_->cfg;
+    const PipelineConfig& c = banded_ ? banded_->cfg : impl_->cfg;
     if (c.grid.width <= 0 || c.grid.height <= 0)
         return Status::error(StatusCode::InvalidArgument, "pipeline: grid dimensions must be positive");
     if (c.grid.tile_width <= 0 || c.grid.tile_height <= 0)
@@ -877,8 +1201,8 @@ Status Pipeline::validate() const {
     return Status::success();
 }
 
-Status Pipeline::ingest(const PointCloud& cloud) { return impl_->ingest(cloud); }
-Status Pipeline::ingest_async(const PointCloud& cloud) { return impl_->ingest(cloud, false); }
+Status Pipeline::ingest(const PointCloud& cloud) { return banded_ ? banded_->ingest(cloud) : impl_->ingest(cloud); }
+Status Pipeline::ingest_async(const PointCloud& cloud) { return banded_ ? banded_->ingest(cloud) : impl_->ingest(cloud, false); }
 
 Status Pipeline::ingest_file(const std::string& path, size_t chunk_points, size_t* points_read) {
     if (points_read) *points_read = 0;
@@ -903,7 +1227,7 @@ Status Pipeline::ingest_file(const std::string& path, size_t chunk_points, size_
     if (points_read) *points_read = total;
     return Status::success();
 }
-Status Pipeline::finalize() { return impl_->finalize(); }
+Status Pipeline::finalize() { return banded_ ? banded_->finalize() : impl_->finalize(); }
 
 Status Pipeline::run(const std::vector<const PointCloud*>& clouds) {
     for (const PointCloud* c : clouds) {
@@ -914,17 +1238,28 @@ Status Pipeline::run(const std::vector<const PointCloud*>& clouds) {
     return finalize();
 }
 
-void Pipeline::set_progress_callback(ProgressCallback cb) { impl_->callback = std::move(cb); }
-const Grid* Pipeline::result() const { return impl_->finalized ? impl_->result.get() : nullptr; }
-ProgressInfo Pipeline::stats() const { return impl_->stats(); }
+void Pipeline::set_progress_callback(ProgressCallback cb) {
+    if (banded_) banded_->callback = std::move(cb);
+    else impl_->callback = std::move(cb);
+}
+const Grid* Pipeline::result() const {
+    if (banded_) return banded_->finalized ? banded_->result.get() : nullptr;
+    return impl_->finalized ? impl_->result.get() : nullptr;
+}
+ProgressInfo Pipeline::stats() const { return banded_ ? banded_->stats() : impl_->stats(); }
 
-int Pipeline::halo_rows() const { return impl_->halo; }
-Status Pipeline::line_reach_rows(const PointCloud& cloud, int* rows) { return impl_->query_line_reach(cloud, rows); }
-int Pipeline::state_row_begin() const { return impl_->hg.state_row0; }
-int Pipeline::state_row_count() const { return impl_->hg.state_rows; }
+// (out of core: no plane lives in HBM between two calls -- the shard accessors answer for "no shard")
+int Pipeline::halo_rows() const { return banded_ ? 0 : impl_->halo; }
+Status Pipeline::line_reach_rows(const PointCloud& cloud, int* rows) {
+    if (banded_) { if (rows) *rows = 0; return Status::success(); }
+    return impl_->query_line_reach(cloud, rows);
+}
+int Pipeline::state_row_begin() const { return banded_ ? 0 : impl_->hg.state_row0; }
+int Pipeline::state_row_count() const { return banded_ ? 0 : impl_->hg.state_rows; }
 
 std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
     std::vector<PlaneView> out;
+    if (banded_) return out;
     {
         Impl::DeviceScope dev(impl_->cfg.cuda_device_id);
         (void)impl_->define_all_planes();               // the caller reads (and may write) them: identity where nothing was ingested
@@ -939,6 +1274,7 @@ std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
 }
 
 void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
+    if (banded_) return nullptr;
     uint32_t* d = nullptr;
     int32_t tx = 0, ty = 0;
     if (pcr_hip_engine_tile_touched(impl_->engine, &d, &tx, &ty) != PCR_HIP_OK) return nullptr;
@@ -947,19 +1283,27 @@ void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
     return d;
 }
 
-Status Pipeline::save_state(const std::string& dir) { return impl_->save_state(dir); }
-Status Pipeline::load_state(const std::string& dir) { return impl_->load_state(dir); }
+Status Pipeline::save_state(const std::string& dir) {
+    if (banded_) return Status::error(StatusCode::NotImplemented, "pipeline: `.pcrt` checkpoints of an out-of-core pipeline are not supported");
+    return impl_->save_state(dir);
+}
+Status Pipeline::load_state(const std::string& dir) {
+    if (banded_) return Status::error(StatusCode::NotImplemented, "pipeline: `.pcrt` checkpoints of an out-of-core pipeline are not supported");
+    return impl_->load_state(dir);
+}
 
-Status Pipeline::synchronize() { return detail::hip_status(pcr_hip_stream_synchronize(impl_->stream)); }
-void* Pipeline::stream_handle() const { return impl_->stream; }
+Status Pipeline::synchronize() { return banded_ ? Status::success() : detail::hip_status(pcr_hip_stream_synchronize(impl_->stream)); }
+void* Pipeline::stream_handle() const { return banded_ ? nullptr : impl_->stream; }
 
 void Pipeline::profile_enable(bool on, const std::string& only_kernel) {
+    if (banded_) return;
     pcr_hip_engine_profile_only(impl_->engine, only_kernel.c_str());
     pcr_hip_engine_profile_enable(impl_->engine, on ? 1 : 0);
 }
 
 std::vector<Pipeline::KernelTime> Pipeline::profile_read(bool reset) {
     std::vector<KernelTime> out;
+    if (banded_) return out;
     pcr_hip_kernel_time buf[32];
     int n = 0;
     if (pcr_hip_engine_profile_read(impl_->engine, buf, 32, &n, reset ? 1 : 0) != PCR_HIP_OK) return out;
@@ -968,6 +1312,7 @@ std::vector<Pipeline::KernelTime> Pipeline::profile_read(bool reset) {
 }
 
 Pipeline::ScatterInfo Pipeline::last_scatter() const {
+    if (banded_) return banded_->last;
     pcr_hip_scatter_stats st{};
     pcr_hip_engine_stats(impl_->engine, &st);
     return {st.path, st.lds_tile_w, st.lds_tile_h, st.lds_apron, st.num_bins,

@@ -181,7 +181,9 @@ void bind_engine(py::module_& m) {
             d["points_valid"] = s.points_valid;
             d["scatter_chunk"] = s.scatter_chunk;
             return d;
-        });
+        })
+        .def("out_of_core", &Pipeline::out_of_core,
+             "True when the grid's state exceeds gpu_memory_budget and the pipeline sweeps it in row bands of whole reference-tile rows");
 
     m.def("pipeline_create_error", &pipeline_create_error,
           "Why the last Pipeline.create() on this thread returned None");
