@@ -1141,6 +1141,9 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
             const int th = g.tile_height;
             const size_t fit = budget / std::max<size_t>(per_row * (size_t)th, 1);          // whole tile rows that fit
             const int band_rows = (int)std::min<size_t>(std::max<size_t>(fit, 1) * (size_t)th, (size_t)g.height + th);
+            if (config.resume)
+                return fail_with(Status::error(StatusCode::NotImplemented,
+                    "pipeline: resume from `.pcrt` checkpoints is not supported for a grid that is processed out of core"));
             if (config.result_location == MemoryLocation::Device)
                 return fail_with(Status::error(StatusCode::InvalidArgument,
                     "pipeline: the grid's state (" + std::to_string(per_row * (size_t)g.height >> 20) + " MB) exceeds the device budget (" +
