@@ -22,6 +22,10 @@
 //                                                                       this point -> null record + the list
 //     static constexpr bool kOwnsX;                                     false: .x = the local centre cell (set by the pass);
 //                                                                       true: make() fills .x as well (kNullCell = nothing to do)
+//     static constexpr bool kFixup;                                     true: make() may return kLater (2) -- "this point needs
+//                                                                       the long way" -- and the Maker has
+//     bool fixup(g, b, routed, pg, i, value, uint4& rec) const;         which the pass calls for those points AFTER its main
+//                                                                       loop, compacted over the workgroup (below)
 // Replaces tile_router_assign_gpu + tile_router_sort_gpu (src/engine/tile_router_kernels.cu:34-293) for glyph clouds.
 #pragma once
 
@@ -35,6 +39,7 @@ constexpr int kCountThreads = 512;
 constexpr int kScatThreads = 512;                         // scatter pass: two workgroups per CU (see chunk_of below)
 constexpr int kVx = 8;                                     // virtual XCDs
 constexpr unsigned kNullCell = 0xFFFFFFFFu;
+constexpr int kLater = 2;                                  // Maker::make of a kFixup Maker: handle this point after the main loop
 constexpr int kItemMax = 8192;                             // tile kernel: records per work item (held in registers while they are ranked)
 
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u; }
@@ -219,6 +224,14 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
               const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor, uint4* __restrict__ records,
               unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count) {
     extern __shared__ unsigned lds_hist[];                  // [nbins]: rank counters, then the run's global start
+    // Makers with a rare long way (kFixup): the points that need it are LISTED in LDS by the unrolled main loop -- which then
+    // holds the short way only -- and handled afterwards by as many lanes as there are such points.  (A rare per-lane branch
+    // inside the unrolled loop is taken by two wave iterations in three when 2 % of the points need it, each time for one or
+    // two lanes, and its code is there once per unrolled point: the Line pass had grown to 14 000 instructions and 361
+    // executed vector instructions per point; with the list 8 200 and 308, A/B in one call 0.67 -> 0.63 ms.)
+    uint2* fix_list = reinterpret_cast<uint2*>(lds_hist + ((b.nbins + 3) & ~3));      // {point offset in the chunk, rank | bin << 16}
+    __shared__ unsigned fix_count;
+    if (threadIdx.x == 0) fix_count = 0;
     for (int i = threadIdx.x; i < b.nbins; i += kScatThreads) lds_hist[i] = 0;
     __syncthreads();
     constexpr int kScatPer = Maker::kPer;                    // points per thread: what the Maker's arithmetic leaves registers for
@@ -255,8 +268,17 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
             const Routed16 r = classify<Maker::kCentre>(g, b, i, wx[u], wy[u], pg);
             if (r.kind != 1) continue;                       // kind 2 was listed by the counting pass
             rank[k] = atomicAdd(&lds_hist[r.bin], 1u) | ((unsigned)r.bin << 16);          // rank < 2^14 (chunk), bin < 2^16
-            if (mk.make(g, b, r, pg, val[u], ch[u], rec[k])) { if (!Maker::kOwnsX) rec[k].x = r.lcell; }   // (kOwnsX: the Maker filled .x itself)
-            else fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;                            // the slot keeps a null record
+            if constexpr (Maker::kFixup) {
+                const int code = mk.make(g, b, r, pg, val[u], ch[u], rec[k]);             // 1 done, 0 list, kLater: the long way
+                if (code == 0) fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;
+                else if (code == kLater) {
+                    fix_list[atomicAdd(&fix_count, 1u)] = make_uint2((unsigned)(i - base), rank[k]);
+                    rec[k].x = kNullCell;                                                   // the slot holds a null record until then
+                }
+            } else {
+                if (mk.make(g, b, r, pg, val[u], ch[u], rec[k])) { if (!Maker::kOwnsX) rec[k].x = r.lcell; }   // (kOwnsX: the Maker filled .x itself)
+                else fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;                        // the slot keeps a null record
+            }
         }
     }
     __syncthreads();
@@ -288,6 +310,21 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
     for (int k = 0; k < kScatPer; ++k) {
         if (rank[k] == 0xFFFFFFFFu) continue;
         records[lds_hist[rank[k] >> 16] + (rank[k] & 0xFFFFu)] = rec[k];
+    }
+    if constexpr (Maker::kFixup) {
+        // the listed points, one per lane: everything is recomputed from the point itself (its x, y, value and channels come
+        // back from the L2), the record overwrites the null record the main loop stored in its slot
+        __syncthreads();                                     // (fix_count is final; orders this workgroup's stores to the slot)
+        const unsigned nfix = fix_count;
+        for (unsigned f = threadIdx.x; f < nfix; f += kScatThreads) {
+            const uint2 e = fix_list[f];
+            const uint64_t i = base + e.x;
+            PointGeom pg;
+            const Routed16 r = classify<Maker::kCentre>(g, b, i, x[i], y[i], pg);          // the same verdict as in the main loop
+            uint4 rc = make_uint4(kNullCell, 0u, 0u, 0u);
+            if (mk.fixup(g, b, r, pg, i, v[i], rc)) records[lds_hist[e.y >> 16] + (e.y & 0xFFFFu)] = rc;
+            else fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;
+        }
     }
 }
 
@@ -354,6 +391,8 @@ int bin(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const Maker& mk,
     if (b.chunk != chunk) return fail(PCR_HIP_INVALID_ARGUMENT, "bin16: BinGeom.chunk must be b16::chunk_of<Maker>()");
     const int blocks = (int)((n + chunk - 1) / chunk);
     const size_t lds = (size_t)b.nbins * 4;
+    // the scatter pass of a kFixup Maker lists up to a whole chunk of points beside its histogram
+    const size_t lds_scatter = Maker::kFixup ? (size_t)((b.nbins + 3) & ~3) * 4 + (size_t)chunk * sizeof(uint2) : lds;
     PCR_HIP_TRY(hipMemsetAsync(U(L.o_cnt), 0, (size_t)kVx * b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_b16_count");
@@ -375,8 +414,8 @@ int bin(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const Maker& mk,
     {
         ScopedKernelTimer t(e, "k_b16_scatter");
         auto go = [&](auto kernel) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kScatThreads), lds, e->stream, gd, b, mk, x, y, v, n,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kScatThreads), lds_scatter, e->stream, gd, b, mk, x, y, v, n,
                                U(L.o_cursor), reinterpret_cast<uint4*>(s + L.o_rec), U(L.o_fbl), U(L.o_fbc));
         };
         go(&k_b16_scatter<Maker>);

@@ -282,6 +282,62 @@ __device__ __forceinline__ LineParams line_params(const GridDev& g, const GlyphD
     return q;
 }
 
+// sin and cos of |a| <= 64 in single precision, ~35 instructions: three-term Cody-Waite reduction by pi/2, the cephes
+// minimax polynomials on [-pi/4, pi/4].  Relative error <= 1.3e-7 (~2 ulp) on that range (checked against numpy over
+// 4e6 random arguments per range, incl. the neighbourhoods of the zeros); larger arguments lose the reduction.
+__device__ __forceinline__ void sincos_f32_small(float a, float& s, float& c) {
+    const float k = rintf(a * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, a);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float sr = fmaf(sp * z, r, r);
+    const float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    const float cr = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s1 : s1;
+    c = ((q + 1) & 2) ? -c1 : c1;
+}
+// The end points of line_params() with a SINGLE-precision sincos instead of the f64 one -- for the binning pass, where the
+// f64 sincos is most of the vector work.  The reference's cosf is the correctly rounded one (sincos_like_libm), so this
+// cd may differ from it by a couple of ulp, which moves an end point by |h| * 6e-7 cells at most: the ROUNDED end points
+// are the reference's unless a coordinate sits that close to a half-integer.  `ambiguous` says so (margin: 6e-7 relative
+// on the product -- 5 ulp -- plus 1e-7 cells), and for directions beyond +-64 rad; the caller then takes line_params().
+// round() rounds halves away from zero, floor(v + 1/2) differs from it on negative halves only -- which are ambiguous by
+// the margin test anyway.  A NaN anywhere is ambiguous (every comparison below fails the other way round).  (The rounding
+// itself in single precision -- the centre converted to f32 -- makes 0.8 % of the points ambiguous at column 4096 and the
+// pass slower again: measured, kept in f64.)
+__device__ __forceinline__ LineParams line_params_fast(const GridDev& g, const GlyphDev& gl, const PointGeom& pg, float val,
+                                                       const GlyphChan& ch, bool& ambiguous) {
+    LineParams q;
+    q.val = val;
+    const float direction = gl.direction ? ch.c0 : gl.def_direction;
+    const float half_len = gl.half_length ? ch.c1 : gl.def_half_length;
+    float hx = half_len * (float)g.inv_csx;
+    float hy = half_len * (float)g.inv_csy;
+    hx = fminf(hx, gl.max_radius);
+    hy = fminf(hy, gl.max_radius);
+    float sd, cd;
+    sincos_f32_small(direction, sd, cd);
+    const float px = hx * cd, py = hy * sd;
+    const double mx = (double)(fabsf(px) * 6e-7f + 1e-7f), my = (double)(fabsf(py) * 6e-7f + 1e-7f);
+    bool ok = fabsf(direction) <= 64.0f;
+    auto rnd = [&](double v, double m, int& out) {
+        const double t = v + 0.5, fl = floor(t), f = t - fl;
+        ok = ok & (f > m) & (f < 1.0 - m);
+        out = (int)fl;
+    };
+    rnd(pg.fcx - (double)px, mx, q.ix0);
+    rnd(pg.fcy - (double)py, my, q.iy0);
+    rnd(pg.fcx + (double)px, mx, q.ix1);
+    rnd(pg.fcy + (double)py, my, q.iy1);
+    q.cx0 = pg.cx0; q.cx1 = pg.cx1; q.cy0 = pg.cy0; q.cy1 = pg.cy1;
+    ambiguous = !ok;
+    return q;
+}
+
 // One LANE walks one segment (integer Bresenham, glyph_kernels.cu:252-278), weight 1 per cell.
 template <typename Sink>
 __device__ __forceinline__ void line_walk(const LineParams& q, Sink& sink) {

@@ -177,6 +177,7 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
 struct LineRecMaker {
     static constexpr bool kCentre = false;
     static constexpr bool kOwnsX = false;
+    static constexpr bool kFixup = false;
     static constexpr int kPer = 12, kBatch = 6;               // the f64 sincos of the end points needs the registers
     GlyphDev gl;
     struct Chan { float dir, hl; };
@@ -278,12 +279,14 @@ k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ re
 // bit-exact against the oracle's walk on every parity case).  So the remainder r_j = (2 j m + M - 1) mod 2M is all the
 // state a step needs:   r += 2m;  if (r >= 2M) { r -= 2M; cell += major + minor } else cell += major   -- 7 instructions.
 // CLIPPING (the centre cell's reference tile, Q4) keeps a CONTIGUOUS range of j (both coordinates are monotone in j): the
-// scatter pass solves it for the few segments that cross their clip rectangle and stores the state at the first kept cell.
+// scatter pass solves it for the few segments that cross their clip rectangle and stores the state at the first kept cell
+// (Maker::fixup: the long way, taken after the pass's main loop by the points make() lists -- bin16.hpp, kFixup).
 // Used when the LDS apron covers the glyph's reach (default half length: every kept cell lies inside the window) and the
 // window's pitch fits an int8 step; the other cases keep the end-point records above.
 struct LineStateMaker {
     static constexpr bool kCentre = false;
     static constexpr bool kOwnsX = true;
+    static constexpr bool kFixup = true;
     static constexpr int kPer = 12, kBatch = 6;               // the f64 sincos of the end points needs the registers
     GlyphDev gl;
     int lw, lh, apron;                                        // the tile kernel's LDS window
@@ -305,8 +308,36 @@ struct LineStateMaker {
         const int num = 2 * M * k - M + 1;
         return num <= 0 ? 0 : div_small(num + 2 * m - 1, 2 * m);
     }
-    __device__ __forceinline__ bool make(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
-                                         float val, const Chan& ch, uint4& rec) const {
+    // The short way (the unrolled main loop of the pass holds nothing else): single-precision sincos, and only segments that
+    // lie inside their clip rectangle whole.  kLater for the others -- an end point that could round the other way with the
+    // reference's correctly rounded cosine (~1e-4 of the points), a segment that crosses its clip rectangle (~2 %) -- and for
+    // anything odd.  The pass is bound by vector instructions executed per point at these tile counts
+    // (profiles/r04_glyph_sq_counters.md).
+    __device__ __forceinline__ int make(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
+                                        float val, const Chan& ch, uint4& rec) const {
+        bool ambiguous;
+        const LineParams q = line_params_fast(g, gl, pg, val, GlyphChan{ch.dir, 0.f, 0.f}, ambiguous);
+        const unsigned udx = (unsigned)max(q.ix0, q.ix1) - (unsigned)min(q.ix0, q.ix1), udy = (unsigned)max(q.iy0, q.iy1) - (unsigned)min(q.iy0, q.iy1);
+        const int wx0 = __mul24(r.bx, b.tile_w) - apron, wy0 = g.st_r0 + b.row0 + __mul24(r.by, b.tile_h) - apron;   // window origin, global cells
+        const int rx0 = max(q.cx0, wx0), rx1 = min(q.cx1, wx0 + lw), ry0 = max(q.cy0, wy0), ry1 = min(q.cy1, wy0 + lh);
+        const bool inside = (min(q.ix0, q.ix1) >= rx0) & (max(q.ix0, q.ix1) < rx1) & (min(q.iy0, q.iy1) >= ry0) & (max(q.iy0, q.iy1) < ry1);
+        if (ambiguous | !inside | (udx > 127u) | (udy > 127u)) return b16::kLater;
+        const int dx = (int)udx, dy = (int)udy;
+        const bool xmajor = dx >= dy;
+        const int M = xmajor ? dx : dy, m = xmajor ? dy : dx;
+        const int sx = q.ix0 < q.ix1 ? 1 : -1, sy = q.iy0 < q.iy1 ? 1 : -1;
+        const unsigned li = (unsigned)(__mul24(q.iy0 - wy0, lw) + (q.ix0 - wx0));
+        const int stepA = xmajor ? sx : sy * lw, stepB = xmajor ? sy * lw : sx;
+        rec.x = li | ((unsigned)(M + 1) << 16) | ((unsigned)max(M - 1, 0) << 24);           // all M + 1 cells, the remainder at j = 0
+        rec.y = __float_as_uint(val);
+        rec.z = (unsigned)max(2 * M, 1) | ((unsigned)(2 * m) << 8) | (((unsigned)stepA & 0xFFu) << 16) | ((unsigned)stepB << 24);
+        return 1;
+    }
+    // The long way, for the points make() passes on (the pass calls it after its main loop, one such point per lane): the
+    // exact end points (f64 sincos, as the reference) and the clip range.
+    __device__ __forceinline__ bool fixup(const GridDev& g, const BinGeom& b, const b16::Routed16& r, const PointGeom& pg,
+                                          uint64_t i, float val, uint4& rec) const {
+        const Chan ch = load(i);
         const LineParams q = line_params(g, gl, pg, val, GlyphChan{ch.dir, 0.f, 0.f});
         // (unsigned differences: a garbage end point -- NaN direction -- must not overflow on its way to the list)
         const unsigned udx = (unsigned)max(q.ix0, q.ix1) - (unsigned)min(q.ix0, q.ix1), udy = (unsigned)max(q.iy0, q.iy1) - (unsigned)min(q.iy0, q.iy1);

@@ -48,6 +48,7 @@ namespace {
 struct GaussCellMaker {
     static constexpr bool kCentre = true;
     static constexpr bool kOwnsX = false;
+    static constexpr bool kFixup = false;
     static constexpr int kPer = 16, kBatch = 16;
     struct Chan {};
     __device__ __forceinline__ Chan load(uint64_t) const { return Chan{}; }

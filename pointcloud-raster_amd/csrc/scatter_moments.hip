@@ -58,6 +58,7 @@ typedef float pcr_f2 __attribute__((ext_vector_type(2)));
 struct MomentMaker {
     static constexpr bool kCentre = true;
     static constexpr bool kOwnsX = false;
+    static constexpr bool kFixup = false;
     static constexpr int kPer = 16, kBatch = 16;
     struct Chan {};
     __device__ __forceinline__ Chan load(uint64_t) const { return Chan{}; }
