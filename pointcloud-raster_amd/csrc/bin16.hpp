@@ -269,6 +269,7 @@ k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, cons
             if (r.kind != 1) continue;                       // kind 2 was listed by the counting pass
             rank[k] = atomicAdd(&lds_hist[r.bin], 1u) | ((unsigned)r.bin << 16);          // rank < 2^14 (chunk), bin < 2^16
             if constexpr (Maker::kFixup) {
+                static_assert(Maker::kOwnsX, "a kFixup Maker fills the whole record, .x included, on both ways");
                 const int code = mk.make(g, b, r, pg, val[u], ch[u], rec[k]);             // 1 done, 0 list, kLater: the long way
                 if (code == 0) fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;
                 else if (code == kLater) {

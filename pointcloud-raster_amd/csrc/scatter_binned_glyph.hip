@@ -320,8 +320,9 @@ struct LineStateMaker {
         const unsigned udx = (unsigned)max(q.ix0, q.ix1) - (unsigned)min(q.ix0, q.ix1), udy = (unsigned)max(q.iy0, q.iy1) - (unsigned)min(q.iy0, q.iy1);
         const int wx0 = __mul24(r.bx, b.tile_w) - apron, wy0 = g.st_r0 + b.row0 + __mul24(r.by, b.tile_h) - apron;   // window origin, global cells
         const int rx0 = max(q.cx0, wx0), rx1 = min(q.cx1, wx0 + lw), ry0 = max(q.cy0, wy0), ry1 = min(q.cy1, wy0 + lh);
-        const bool inside = (min(q.ix0, q.ix1) >= rx0) & (max(q.ix0, q.ix1) < rx1) & (min(q.iy0, q.iy1) >= ry0) & (max(q.iy0, q.iy1) < ry1);
-        if (ambiguous | !inside | (udx > 127u) | (udy > 127u)) return b16::kLater;
+        // (integer ands / ors on purpose: no short-circuit branches in the unrolled loop)
+        const int inside = (int)(min(q.ix0, q.ix1) >= rx0) & (int)(max(q.ix0, q.ix1) < rx1) & (int)(min(q.iy0, q.iy1) >= ry0) & (int)(max(q.iy0, q.iy1) < ry1);
+        if ((int)ambiguous | (inside ^ 1) | (int)(udx > 127u) | (int)(udy > 127u)) return b16::kLater;
         const int dx = (int)udx, dy = (int)udy;
         const bool xmajor = dx >= dy;
         const int M = xmajor ? dx : dy, m = xmajor ? dy : dx;
