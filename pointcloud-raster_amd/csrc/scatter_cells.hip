@@ -460,10 +460,13 @@ bool cells_gauss_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t
     const int bins_x = (g.W + p.tile_w - 1) / p.tile_w;
     const int band_rows = band_rows_for(g, p.tile_w, p.tile_h, b16::max_bins(e));
     if (band_rows <= 0) return false;
-    // every band is a full pass over the points: beyond two the two-level sort of the index-record form reads less
+    // Every band is a full pass over the points (count + scatter: ~12 us per million points and band), the cell tiles
+    // themselves cost ~28 us per million points, the index-record tiles behind the two-level sort ~83 (the full-size two-rank
+    // rehearsals, profiles/r04_c5_rehearsal_2ranks_one_gpu.json: a 16384 x 8192 shard, four bands, 75.7 against 82.9 ms per
+    // 500 M points with both ranks on one GPU): the sweep wins up to four bands.  Round 3 stopped at two.
     (void)bins_x;
     const int nbands = (g.st_rows + band_rows - 1) / band_rows;
-    if (nbands > (e->max_bins == kMaxBins ? 2 : kMaxBands)) return false;
+    if (nbands > (e->max_bins == kMaxBins ? 4 : kMaxBands)) return false;
     // every tile's window is swept once per scatter: not worth it for a handful of points
     const uint64_t cells = (uint64_t)g.W * g.st_rows;
     if (e->forced_path != 2 && e->stats.points_in * 64 < cells) return false;
