@@ -416,20 +416,35 @@ k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ 
                 const BinItem* __restrict__ items, const unsigned* __restrict__ n_items) {
     extern __shared__ double lds_win[];                      // (the whole segment is dynamic: no static LDS in this kernel)
     if (blockIdx.x >= *n_items) return;
+    // Both planes wanted (WeightedAverage / Average): ONE 64-bit word per cell and ONE ds_add_u64 per visited cell,
+    //     word = visits << 48 | sum of (q + 2^31),    q = the value as a signed multiple of 2^(e_lo - 150), |q| < 2^31
+    // -- an item holds at most 65 535 records and a segment visits a cell once, so neither field can carry into the other;
+    // the sum of the q is the low field minus visits * 2^31, exact.  |q| < 2^31 leaves a window of EIGHT binary exponents
+    // (24 significand bits shifted by up to 7), set from the largest exponent among the item's first 1024 values: on U(0, 1)
+    // values 0.4 % of the segments do not fit.  Those count in pass 0 (q = 0) and are LISTED in LDS; the item then decodes
+    // its words into the count plane and a plane of doubles and walks the listed segments with ds_add_f64 (a list that
+    // overflows: the whole item is scanned again for them).  The LDS pipe is the kernel's bound (29 cycles a step for
+    // ds_add_u64 + ds_add_u32 on 64 unrelated cells, 12-14 for the ds_add_u64 alone: tools/ubench_lds_region.hip).
+    constexpr bool PACK = MASK == 3u;
+    constexpr int kWindow = PACK ? 7 : 22;                   // accepted exponents: [e_lo, e_lo + kWindow]
     const BinItem it = items[blockIdx.x];
     const int cells = t.lw * t.lh;                           // <= kLineMaxCells (checked on the host)
     char* lds = reinterpret_cast<char*>(lds_win);
     int* s_ehi = reinterpret_cast<int*>(lds);
-    int* s_redo = s_ehi + 1;
+    int* s_redo = s_ehi + 1;                                 // 1: some segment was left out of the fixed-point sums; 2: and the list is full
+    unsigned* s_nlist = reinterpret_cast<unsigned*>(s_ehi + 2);
     unsigned* t_c = reinterpret_cast<unsigned*>(lds + kLineCountBase);
     unsigned long long* t_q = reinterpret_cast<unsigned long long*>(lds + kLineSumBase);
     double* t_s = reinterpret_cast<double*>(lds + kLineSumBase);
+    // the left-out segments of the item (record numbers): between the count plane and the sum plane
+    unsigned* list = t_c + cells;
+    const unsigned list_cap = (unsigned)((kLineSumBase - kLineCountBase) / 4 - cells);
     const uint4* rec = records + it.first;
     const uint4 first = threadIdx.x < it.count ? stream_load(rec + threadIdx.x) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
-    if (threadIdx.x == 0) { *s_ehi = 0; *s_redo = 0; }
+    if (threadIdx.x == 0) { *s_ehi = 0; *s_redo = 0; *s_nlist = 0u; }
     for (int i = threadIdx.x; i < cells; i += kThreads) {
         if (MASK & 1) t_q[i] = 0ull;
-        if (MASK & 2) t_c[i] = 0u;
+        if ((MASK & 2) && !PACK) t_c[i] = 0u;
     }
     __syncthreads();
     int e_lo = 0;
@@ -437,99 +452,135 @@ k_tile_line_rec(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ 
         int e = 0;
         if (first.x != b16::kNullCell) {
             e = (int)((first.y >> 23) & 0xFFu);
-            if (e == 255) e = 0;                             // NaN / inf: found again (and flagged) by the walk
+            if (e == 255) e = 0;                             // NaN / inf: found again (and listed) by the walk
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) e = max(e, __shfl_xor(e, off, 64));
         if ((threadIdx.x & 63) == 0 && e > 0) atomicMax(s_ehi, e);
         __syncthreads();
-        e_lo = *s_ehi + 3 - 22;                              // accepted exponents: [e_lo, e_lo + 22], normal numbers only
+        // unpacked: room for values 8 x larger than the first 1024, and down to 2^-19 of them; packed: the window is too
+        // short for head room -- a later, larger value is listed
+        e_lo = PACK ? *s_ehi - kWindow : *s_ehi + 3 - kWindow;
     }
+    auto fits_window = [&](unsigned bits) {
+        const int e = (int)((bits >> 23) & 0xFFu);
+        return (bits & 0x7FFFFFFFu) == 0u || (e != 255 && e >= max(e_lo, 1) && e <= e_lo + kWindow);
+    };
     // The walk's whole state in ONE register: st = (byte offset of the cell in the count plane) << 16 | remainder.
     //   minor step taken  <=>  remainder >= 2M - 2m;   st += taken ? d1 : d0
     //   d0 = (4 major) << 16 | 2m        d1 = (4 (major + minor)) << 16 + 2m - 2M        (plain 32-bit adds: no field borrows)
     // Both plane addresses are shifts of st (the remainder stays below 2^15, so bit 15 -- bit 0 of st >> 15 -- is clear).
     // Up to the shortest segment of the wave no lane needs masking; the steps there are unrolled by four.
-    // pass 0: count plane + fixed-point sums of the values that fit; pass 1 (only when some did not): those, as doubles
-    auto walk = [&](auto pass_c) {
+    // pass 0: visits + fixed-point sums of the values that fit; pass 1 (only when some did not): those, as doubles
+    auto walk_wave = [&](auto pass_c, const uint4 cur, bool valid, unsigned recno) {
         constexpr int PASS = decltype(pass_c)::value;
+        bool fits = true;
+        if (MASK & 1) fits = fits_window(cur.y);
+        if (PASS == 1) valid = valid && !fits;               // the second pass walks only what the first left out
+        const unsigned n = valid ? (cur.x >> 16) & 0xFFu : 0u;
+        const unsigned M2 = cur.z & 0xFFu, m2 = (cur.z >> 8) & 0xFFu;
+        const int sA4 = 4 * (int)(signed char)((cur.z >> 16) & 0xFFu), sB4 = 4 * (int)(signed char)(cur.z >> 24);
+        unsigned st = ((cur.x & 0xFFFFu) << 18) | (cur.x >> 24);
+        const unsigned thr = M2 - m2;
+        const unsigned d0 = ((unsigned)sA4 << 16) + m2, d1 = ((unsigned)(sA4 + sB4) << 16) + m2 - M2;
+        const double dv = (double)__uint_as_float(cur.y);
+        unsigned long long q = 0ull;
+        if ((MASK & 1) && PASS == 0) {
+            const int e = (int)((cur.y >> 23) & 0xFFu);
+            const bool zero = (cur.y & 0x7FFFFFFFu) == 0u;
+            if (n > 0 && !fits) {
+                const unsigned k = atomicAdd(s_nlist, 1u);
+                if (k < list_cap) list[k] = recno;
+                atomicMax(s_redo, k < list_cap ? 1 : 2);
+            }
+            const long long mag = zero || !fits ? 0ll : (long long)((cur.y & 0x7FFFFFu) | 0x800000u) << (e - e_lo);
+            q = (unsigned long long)((cur.y >> 31) ? -mag : mag);
+            if (PACK) q += (1ull << 48) + (1ull << 31);
+        }
+        auto step = [&]() {
+            if (MASK & 1) {
+                char* ps = lds + kLineSumBase + (st >> 15);
+                if (PASS == 0) atomicAdd(reinterpret_cast<unsigned long long*>(ps), q);
+                else unsafeAtomicAdd(reinterpret_cast<double*>(ps), dv);
+            }
+            if ((MASK & 2) && !PACK && PASS == 0) atomicAdd(reinterpret_cast<unsigned*>(lds + kLineCountBase + (st >> 16)), 1u);
+        };
+        auto advance = [&]() { st += (st & 0xFFFFu) >= thr ? d1 : d0; };
+        // the shortest and the longest walk of the wave (null records: none / 0)
+        unsigned nmin = valid ? n : 0xFFFFu, nmax = n;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            nmin = min(nmin, (unsigned)__shfl_xor((int)nmin, off, 64));
+            nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, off, 64));
+        }
+        nmin = __builtin_amdgcn_readfirstlane(nmin);
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        if (nmin > nmax) nmin = 0;                        // (a wave of null records)
+        unsigned j = 0;
+        if (valid) {
+            for (; j + 4 <= nmin; j += 4) {
+                step(); advance(); step(); advance(); step(); advance(); step(); advance();
+            }
+            for (; j < nmin; ++j) { step(); advance(); }
+        }
+        j = nmin;
+        for (; j < nmax; ++j) {
+            if (j < n) step();
+            advance();
+        }
+    };
+    auto walk = [&](auto pass_c) {
         uint4 cur = first;
         for (unsigned j0 = 0; j0 < it.count; j0 += kThreads) {
             const unsigned jn = j0 + kThreads + threadIdx.x;
             const uint4 nxt = jn < it.count ? stream_load(rec + jn) : make_uint4(b16::kNullCell, 0u, 0u, 0u);
-            bool valid = cur.x != b16::kNullCell;
-            bool fits = true;
-            if (MASK & 1) {
-                const int e = (int)((cur.y >> 23) & 0xFFu);
-                fits = (cur.y & 0x7FFFFFFFu) == 0u || (e != 255 && e >= max(e_lo, 1) && e <= e_lo + 22);
-            }
-            if (PASS == 1) valid = valid && !fits;           // the second pass walks only what the first left out
-            const unsigned n = valid ? (cur.x >> 16) & 0xFFu : 0u;
-            const unsigned M2 = cur.z & 0xFFu, m2 = (cur.z >> 8) & 0xFFu;
-            const int sA4 = 4 * (int)(signed char)((cur.z >> 16) & 0xFFu), sB4 = 4 * (int)(signed char)(cur.z >> 24);
-            unsigned st = ((cur.x & 0xFFFFu) << 18) | (cur.x >> 24);
-            const unsigned thr = M2 - m2;
-            const unsigned d0 = ((unsigned)sA4 << 16) + m2, d1 = ((unsigned)(sA4 + sB4) << 16) + m2 - M2;
-            const double dv = (double)__uint_as_float(cur.y);
-            unsigned long long q = 0ull;
-            if ((MASK & 1) && PASS == 0) {
-                const int e = (int)((cur.y >> 23) & 0xFFu);
-                const bool zero = (cur.y & 0x7FFFFFFFu) == 0u;
-                if (n > 0 && !fits) *s_redo = 1;             // (benign race: every writer stores 1)
-                const long long mag = zero || !fits ? 0ll : (long long)((cur.y & 0x7FFFFFu) | 0x800000u) << (e - e_lo);
-                q = (unsigned long long)((cur.y >> 31) ? -mag : mag);
-            }
-            auto step = [&]() {
-                if (MASK & 1) {
-                    char* ps = lds + kLineSumBase + (st >> 15);
-                    if (PASS == 0) atomicAdd(reinterpret_cast<unsigned long long*>(ps), q);
-                    else unsafeAtomicAdd(reinterpret_cast<double*>(ps), dv);
-                }
-                if ((MASK & 2) && PASS == 0) atomicAdd(reinterpret_cast<unsigned*>(lds + kLineCountBase + (st >> 16)), 1u);
-            };
-            auto advance = [&]() { st += (st & 0xFFFFu) >= thr ? d1 : d0; };
-            // the shortest and the longest walk of the wave (null records: none / 0)
-            unsigned nmin = valid ? n : 0xFFFFu, nmax = n;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                nmin = min(nmin, (unsigned)__shfl_xor((int)nmin, off, 64));
-                nmax = max(nmax, (unsigned)__shfl_xor((int)nmax, off, 64));
-            }
-            nmin = __builtin_amdgcn_readfirstlane(nmin);
-            nmax = __builtin_amdgcn_readfirstlane(nmax);
-            if (nmin > nmax) nmin = 0;                        // (a wave of null records)
-            unsigned j = 0;
-            if (valid) {
-                for (; j + 4 <= nmin; j += 4) {
-                    step(); advance(); step(); advance(); step(); advance(); step(); advance();
-                }
-                for (; j < nmin; ++j) { step(); advance(); }
-            }
-            j = nmin;
-            for (; j < nmax; ++j) {
-                if (j < n) step();
-                advance();
-            }
+            walk_wave(pass_c, cur, cur.x != b16::kNullCell, j0 + threadIdx.x);
             cur = nxt;
         }
     };
     walk(std::integral_constant<int, 0>{});
     __syncthreads();
     const double scale = ldexp(1.0, e_lo - 150);
-    const bool redo = (MASK & 1) && *s_redo != 0;
+    auto unpack_sum = [&](unsigned long long w) {             // the sum of the q of a packed word
+        return (long long)(w & 0xFFFFFFFFFFFFull) - ((long long)(w >> 48) << 31);
+    };
+    const int redo = (MASK & 1) ? *s_redo : 0;
     if (redo) {
-        for (int i = threadIdx.x; i < cells; i += kThreads) t_s[i] = (double)(long long)t_q[i] * scale;
+        for (int i = threadIdx.x; i < cells; i += kThreads) {
+            const unsigned long long w = t_q[i];
+            if (PACK) t_c[i] = (unsigned)(w >> 48);
+            t_s[i] = (double)(PACK ? unpack_sum(w) : (long long)w) * scale;
+        }
         __syncthreads();
-        walk(std::integral_constant<int, 1>{});
+        if (redo == 1) {                                      // the listed segments, one per lane (their records come back from the L2)
+            const unsigned nl = *s_nlist;
+            for (unsigned k0 = 0; k0 < nl; k0 += kThreads) {
+                const unsigned k = k0 + threadIdx.x;
+                uint4 cur = make_uint4(b16::kNullCell, 0u, 0u, 0u);
+                if (k < nl) cur = rec[list[k]];
+                walk_wave(std::integral_constant<int, 1>{}, cur, cur.x != b16::kNullCell, 0u);
+            }
+        } else {
+            walk(std::integral_constant<int, 1>{});
+        }
         __syncthreads();
     }
-    const bool fixed = (MASK & 1) && !redo;
     const int bx = it.bin % t.bins.bins_x, by = it.bin / t.bins.bins_x;
     const int x0 = bx * t.bins.tile_w - t.apron, y0 = t.bins.row0 + by * t.bins.tile_h - t.apron;      // window origin; rows relative to the state window
     for (int i = threadIdx.x; i < cells; i += kThreads) {
         double s = 0.0;
-        if (MASK & 1) s = fixed ? (double)(long long)t_q[i] * scale : t_s[i];
-        unsigned c = (MASK & 2) ? t_c[i] : 0u;
+        unsigned c = 0u;
+        if (redo) {
+            if (MASK & 1) s = t_s[i];
+            if (MASK & 2) c = t_c[i];
+        } else if (PACK) {
+            const unsigned long long w = t_q[i];
+            c = (unsigned)(w >> 48);
+            s = (double)unpack_sum(w) * scale;
+        } else {
+            if (MASK & 1) s = (double)(long long)t_q[i] * scale;
+            if (MASK & 2) c = t_c[i];
+        }
         if (s == 0.0 && c == 0u) continue;
         int ly = i / t.lw, lx = i - ly * t.lw;
         int64_t cell = (int64_t)(y0 + ly) * g.W + (x0 + lx);     // non-zero cells were clipped to the grid by the scatter pass
@@ -668,7 +719,7 @@ int binned_glyph(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pla
     int band_rows = 0;
     if (!glyph_tile(e, gl, mask, &t, &band_rows)) return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: grid cannot be binned");
     // work item size: ~4 M cell updates per workgroup for the Gaussian, 64 K segments for the Line
-    unsigned item_points = 65536;
+    unsigned item_points = 65535;                             // (k_tile_line_rec counts a cell's visits in 16 bits)
     if (gl.type == PCR_HIP_GLYPH_GAUSSIAN) {
         double fp = (2.0 * t.need + 1.0) * (2.0 * t.need + 1.0);
         item_points = (unsigned)std::min(65536.0, std::max(1024.0, 4.0e6 / fp));

@@ -186,15 +186,42 @@ def test_random_large_gaussians_on_the_matrix_core_pass(A, seed):
           f"sigma {sx:.2f},{sy:.2f} r<={maxr} {rname}", scale=1.0 if rname == "Count" else 10.0)
 
 
-@pytest.mark.parametrize("spread", ["one_exponent", "seven_exponents", "wide", "nonfinite"])
+def test_line_tiles_count_field_holds_a_full_item(A):
+    """The packed Line window counts a cell's visits in 16 bits: 70 000 identical segments (two work items, the first with the
+    65 535 records an item may hold) put 65 535 visits on every cell of the segment without carrying into nothing."""
+    W, H, n = 200, 200, 70000
+    og = O.make_grid((0.0, 0.0, float(W), float(H)))
+    rng = np.random.default_rng(5)
+    x, y = np.full(n, 100.3), np.full(n, 90.6)
+    d = np.full(n, 0.4, dtype=np.float32)
+    v = rng.uniform(0.5, 1.0, n).astype(np.float32)
+    gl = dict(type=A.GLYPH_LINE, half_length=6.0, max_radius=8.0)
+    ogl = O.make_glyph(O.GLYPH_LINE, half_length=6.0, max_radius=8.0)
+    grid = A.make_grid((0.0, 0.0, float(W), float(H)), dims=(W, H))
+    run = A.ReductionRun(grid, 3, path=2)
+    try:
+        run.scatter(x, y, v, glyph=gl, direction=d)
+        got_s, got_c = run.plane("d_sum").astype(np.float64), run.plane("d_wgt")
+        assert run.stats().path == 1
+    finally:
+        run.close()
+    want_c = np.nan_to_num(O.run(og, RT["Count"], x, y, v, glyph=ogl, direction=d))
+    assert want_c.max() == n and np.array_equal(got_c, want_c)
+    exact = O.run(og, RT["Sum"], x, y, v, glyph=ogl, direction=d, wide=True).astype(np.float64)
+    assert np.allclose(got_s, exact, rtol=4e-7, atol=0.0)
+
+
+@pytest.mark.parametrize("spread", ["one_exponent", "seven_exponents", "wide", "wide_dense", "nonfinite"])
 def test_line_tiles_packed_and_f64_forms_agree_with_the_oracle(A, spread):
     """Line tiles sum values in f64 inside their LDS window and round once at the merge: a cell whose values are all tiny next to
     its neighbours' keeps its full relative precision (the check is relative to the cell's own sum of |v|), whatever the spread
     of exponents inside a tile, and NaN / inf values stay where the reference puts them.  (Round 3 tried two integer forms of
     the window -- visits and value packed in one 64-bit atomic; the value as exact 64-bit fixed point with an f64 redo -- both
-    green on this test, neither faster: the tile kernel is bound by bank conflicts of its random LDS atomics, not by the
-    adder.  DESIGN section 9.)"""
-    W, H, n = 400, 300, 40000
+    green on this test, neither faster: the tile kernel was bound by its walk then.  Round 4's kernel IS the packed form for
+    two planes: one ds_add_u64 per visited cell, an eight-exponent window, the values outside it listed in LDS and walked as
+    doubles afterwards -- "wide" lists ~half of an item's segments, "wide_dense" more than the list holds: the item is scanned
+    again for them.  DESIGN section 3a.)"""
+    W, H, n = 400, 300, (400000 if spread == "wide_dense" else 40000)
     og = O.make_grid((0.0, 0.0, float(W), float(H)))
     rng = np.random.default_rng(31)
     x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
