@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define PCR_HIP_ABI_VERSION 3   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2 */
+#define PCR_HIP_ABI_VERSION 4   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2;
+                                 * 4: + engine_finalize_with_scatter / engine_finalize_taken / finalize_group_unless */
 
 typedef enum pcr_hip_status {
     PCR_HIP_OK = 0,
@@ -174,6 +175,11 @@ int pcr_hip_finalize(int rtype, const pcr_hip_grid* g, const pcr_hip_planes* pla
 #define PCR_HIP_MAX_FINALIZE_OUTPUTS 8
 int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
                            int n_out, const int* rtypes, float* const* d_outs, pcr_hip_stream s);
+/* Same, but a no-op when the device word *d_bands_done is non-zero at the time the kernel runs (NULL: always runs):
+ * the bands were already written by the scatter that defined the planes (pcr_hip_engine_finalize_with_scatter). */
+int pcr_hip_finalize_group_unless(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
+                                  int n_out, const int* rtypes, float* const* d_outs, const uint32_t* d_bands_done,
+                                  pcr_hip_stream s);
 
 /* ---- scatter engine.  replaces: TileRouter::assign + sort + extract_batches
  *      (include/pcr/engine/tile_router_kernels.h:15-52, src/engine/tile_router.cpp:51-366),
@@ -206,6 +212,19 @@ int pcr_hip_engine_set_path(pcr_hip_engine* e, int path);
  * The reference initialises tile state inside ingest, on first acquire (src/engine/tile_manager.cpp:272-320,
  * src/engine/pipeline.cpp:688-691): with 2 this build's state initialisation is inside the ingest as well. */
 int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh);
+/* Finalize fused into the scatter that defines the planes -- for the NEXT pcr_hip_scatter_point only (cleared by it).
+ * When that scatter runs with planes_fresh = 2 on the binned path and its tile pass stores every cell of the state
+ * window itself, the same pass also stores the finished bands (finalize(rtype) of the cell where its reference tile is
+ * touched BY THIS SCATTER'S points, NaN elsewhere) from the LDS tile it has in hand: the planes are not read again
+ * (Pipeline::finalize after a pipeline's only ingest: src/engine/pipeline.cpp:1154-1286 reads every tile's state back).
+ * d_outs[i] holds own_rows * width floats, 16-byte aligned; the engine's owned rows must be its whole state window.
+ * *d_bands_done (device word) is written by the scatter: 1 when every band cell was stored, 0 when the pass could not
+ * (a bin the scan had to split).  pcr_hip_engine_finalize_taken: 1 when the last pcr_hip_scatter_point launched the
+ * fused form at all (else *d_bands_done was not written and the bands are untouched).  The bands stay valid only while
+ * nothing else changes the planes or the touched flags: the caller decides (pcr_hip_finalize_group_unless). */
+int pcr_hip_engine_finalize_with_scatter(pcr_hip_engine* e, int n_out, const int* rtypes, float* const* d_outs,
+                                         uint32_t* d_bands_done);
+int pcr_hip_engine_finalize_taken(const pcr_hip_engine* e);
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out);
 /* device array of tiles_x*tiles_y words, non-zero where a valid point's centre cell fell */
 int pcr_hip_engine_tile_touched(pcr_hip_engine* e, uint32_t** d_tile_touched, int32_t* tiles_x, int32_t* tiles_y);

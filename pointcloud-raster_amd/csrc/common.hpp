@@ -50,6 +50,23 @@ struct PlanesDev {
     float* mn;
 };
 
+// Several reductions over one group's planes in one sweep (k_finalize_group; the Point tile pass when it also finalizes).
+struct FinalizeOuts {
+    int n;
+    int rtype[PCR_HIP_MAX_FINALIZE_OUTPUTS];
+    float* out[PCR_HIP_MAX_FINALIZE_OUTPUTS];
+};
+
+__device__ __forceinline__ float finalize_rt(int rt, float s, float w, float mx, float mn) {
+    switch (rt) {
+        case PCR_HIP_SUM: return s;
+        case PCR_HIP_COUNT: return w > 0.0f ? w : NAN;
+        case PCR_HIP_MAX: return mx == -FLT_MAX ? NAN : mx;
+        case PCR_HIP_MIN: return mn == FLT_MAX ? NAN : mn;
+        default: return w > 0.0f ? s / w : NAN;
+    }
+}
+
 struct GlyphDev {
     int type;
     float def_direction, def_half_length, def_sigma_x, def_sigma_y, def_rotation, max_radius;

@@ -265,6 +265,28 @@ int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh) {
     return PCR_HIP_OK;
 }
 
+int pcr_hip_engine_finalize_with_scatter(pcr_hip_engine* e, int n_out, const int* rtypes, float* const* d_outs,
+                                         uint32_t* d_bands_done) {
+    PCR_REQUIRE(e, "engine_finalize_with_scatter: null engine");
+    e->fused_outs.n = 0;
+    e->fused_done = nullptr;
+    if (n_out == 0) return PCR_HIP_OK;                    // withdraws the hint
+    PCR_REQUIRE(rtypes && d_outs && d_bands_done, "engine_finalize_with_scatter: null argument");
+    PCR_REQUIRE(n_out >= 1 && n_out <= PCR_HIP_MAX_FINALIZE_OUTPUTS, "engine_finalize_with_scatter: 1..8 outputs");
+    for (int i = 0; i < n_out; ++i) {
+        PCR_REQUIRE(rtypes[i] >= PCR_HIP_SUM && rtypes[i] <= PCR_HIP_COUNT, "pipeline: unknown reduction type");
+        PCR_REQUIRE(d_outs[i] && (reinterpret_cast<uintptr_t>(d_outs[i]) & 15) == 0,
+                    "engine_finalize_with_scatter: bands must be non-null and 16-byte aligned");
+        e->fused_outs.rtype[i] = rtypes[i];
+        e->fused_outs.out[i] = d_outs[i];
+    }
+    e->fused_outs.n = n_out;
+    e->fused_done = d_bands_done;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_engine_finalize_taken(const pcr_hip_engine* e) { return e && e->fused_taken ? 1 : 0; }
+
 int pcr_hip_engine_stats(const pcr_hip_engine* e, pcr_hip_scatter_stats* out) {
     PCR_REQUIRE(e && out, "engine_stats: null argument");
     unsigned long long c[8] = {0};
@@ -336,6 +358,11 @@ int pcr_hip_engine_profile_read(pcr_hip_engine* e, pcr_hip_kernel_time* out, int
 int pcr_hip_scatter_point(pcr_hip_engine* e, uint32_t plane_mask, const pcr_hip_planes* planes,
                           const double* d_x, const double* d_y, const float* d_value, uint64_t n) {
     PCR_REQUIRE(e, "scatter_point: null engine");
+    struct HintGuard {                                    // the fused-finalize hint covers this call, however it ends
+        pcr_hip_engine* e;
+        ~HintGuard() { e->fused_outs.n = 0; e->fused_done = nullptr; }
+    } hint_guard{e};
+    e->fused_taken = false;
     PlanesDev pl;
     int rc = check_planes(plane_mask, planes, 15u, pl);
     if (rc) return rc;

@@ -29,6 +29,11 @@ struct pcr_hip_engine {
                                                // contributions, 1 they hold identity values, 2 they are UNDEFINED (the
                                                // scatter defines every cell of the state window, see engine.hip)
 
+    // pcr_hip_engine_finalize_with_scatter, for the NEXT Point scatter: bands its tile pass may store (scatter_binned.hip)
+    pcrhip::FinalizeOuts fused_outs{};
+    uint32_t* fused_done = nullptr;
+    bool fused_taken = false;
+
     // optional per-kernel event timing
     bool profiling = false;
     std::string profile_only;                  // non-empty: only launches timed under this name are bracketed by events

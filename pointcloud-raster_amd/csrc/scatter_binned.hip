@@ -522,11 +522,17 @@ inline BinGeom point_bin_geom(const GridDev& g, uint32_t mask, int row0, int row
     return b;
 }
 
-template <unsigned MASK>
+// FUSED (pcr_hip_engine_finalize_with_scatter): a launch that defines every cell of undefined planes also stores the finished
+// bands -- finalize(rtype) of the cell where its reference tile is touched, NaN elsewhere -- from the tile it has in hand, so
+// that the finalize pass does not read the planes back (C2: 134 MB).  The touched flags are complete: the counting pass of
+// this scatter set them.  *done tells the finalize call whether the bands were stored (not when the scan split a bin).
+template <unsigned MASK, bool FUSED>
 __global__ void __launch_bounds__(kThreads)
 k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ records,
-             const BinItem* __restrict__ items, const unsigned* __restrict__ n_items, int fresh) {
+             const BinItem* __restrict__ items, const unsigned* __restrict__ n_items, int fresh,
+             FinalizeOuts fo, const uint32_t* __restrict__ touched, uint32_t* __restrict__ done) {
     extern __shared__ double lds_tile[];
+    if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) *done = (fresh == 2 && n_items[1] == 0u) ? 1u : 0u;
     if (blockIdx.x >= *n_items) return;
     // fresh: 0 the planes hold earlier contributions (read-modify-write); 1 they hold identity values (the merge stores where
     // the tile has something); 2 they are UNDEFINED and this launch has an item for every bin: every cell is stored, the
@@ -633,6 +639,23 @@ k_tile_accum(GridDev g, BinGeom b, PlanesDev pl, const uint2* __restrict__ recor
                 __builtin_nontemporal_store(f4v{g2.x, g2.y, g2.z, g2.w}, reinterpret_cast<f4v*>(pl.wgt + cell)); }
             if ((MASK & 4) && n4) { g4.x = fmaxf(g4.x, a4.x); g4.y = fmaxf(g4.y, a4.y); g4.z = fmaxf(g4.z, a4.z); g4.w = fmaxf(g4.w, a4.w); *reinterpret_cast<float4*>(pl.mx + cell) = g4; }
             if ((MASK & 8) && n8) { g8.x = fminf(g8.x, a8.x); g8.y = fminf(g8.y, a8.y); g8.z = fminf(g8.z, a8.z); g8.w = fminf(g8.w, a8.w); *reinterpret_cast<float4*>(pl.mn + cell) = g8; }
+            if (FUSED && full) {
+                // (the owned rows are the state window: a band cell has the plane cell's index)
+                const float s4[4] = {g1.x, g1.y, g1.z, g1.w}, w4[4] = {g2.x, g2.y, g2.z, g2.w};
+                const float x4[4] = {g4.x, g4.y, g4.z, g4.w}, m4[4] = {g8.x, g8.y, g8.z, g8.w};
+                const int trow = ((g.st_r0 + r0 + ly) / g.th) * g.tiles_x;
+                bool live[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) live[k] = touched[trow + (c0 + lx + k) / g.tw] != 0u;
+                for (int o = 0; o < fo.n; ++o) {
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[k] = live[k] ? finalize_rt(fo.rtype[o], (MASK & 1) ? s4[k] : 0.f, (MASK & 2) ? w4[k] : 0.f,
+                                                     (MASK & 4) ? x4[k] : -FLT_MAX, (MASK & 8) ? m4[k] : FLT_MAX) : NAN;
+                    __builtin_nontemporal_store(f4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4v*>(fo.out[o] + cell));
+                }
+            }
         }
         return;
     }
@@ -677,13 +700,17 @@ k_fill_if(const unsigned* __restrict__ n_items, PlanesDev pl, unsigned mask, int
 }
 
 template <unsigned MASK>
-void launch_accum(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const PlanesDev& pl, const BinBuffers& bb) {
+void launch_accum(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const PlanesDev& pl, const BinBuffers& bb,
+                  bool fused = false) {
     size_t lds = (size_t)b.tile_w * b.tile_h * tile_cell_bytes(MASK);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_accum<MASK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // fresh: only when every bin is owned by one workgroup of this launch can a store replace the read-modify-write
-    hipLaunchKernelGGL((k_tile_accum<MASK>), dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, b, pl,
-                       bb.records, bb.items, bb.n_items, e->planes_fresh);
+    auto go = [&](auto kernel, const FinalizeOuts& fo, uint32_t* done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(bb.max_items), dim3(kThreads), lds, e->stream, gd, b, pl,
+                           bb.records, bb.items, bb.n_items, e->planes_fresh, fo, (const uint32_t*)e->d_touched, done);
+    };
+    if (fused) go(&k_tile_accum<MASK, true>, e->fused_outs, e->fused_done);
+    else go(&k_tile_accum<MASK, false>, FinalizeOuts{}, nullptr);
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -901,9 +928,14 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
         if (rc) return rc;
         if (define_all)
             hipLaunchKernelGGL(k_fill_if, dim3(2048), dim3(256), 0, e->stream, bb.n_items, pl, mask, cells / 4);
+        // the bands too, when the caller asked (pcr_hip_engine_finalize_with_scatter): this launch stores every cell of the
+        // window from float4 groups (define_all), and a band cell has the plane cell's index when the owned rows are the window
+        const bool fused = define_all && e->fused_outs.n > 0 && e->fused_done && e->gd.W % 4 == 0 &&
+                           e->gd.own_r0 == e->gd.st_r0 && e->gd.own_r1 - e->gd.own_r0 == e->gd.st_rows;
+        e->fused_taken = fused;
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {
-#define PCR_ACC(M) case M: launch_accum<M>(e, gd, b, pl, bb); break;
+#define PCR_ACC(M) case M: launch_accum<M>(e, gd, b, pl, bb, fused); break;
             PCR_ACC(1) PCR_ACC(2) PCR_ACC(3) PCR_ACC(4) PCR_ACC(5) PCR_ACC(6) PCR_ACC(7) PCR_ACC(8)
             PCR_ACC(9) PCR_ACC(10) PCR_ACC(11) PCR_ACC(12) PCR_ACC(13) PCR_ACC(14) PCR_ACC(15)
 #undef PCR_ACC

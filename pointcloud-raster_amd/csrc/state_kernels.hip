@@ -117,26 +117,13 @@ k_finalize(GridDev g, const float* __restrict__ pa, const float* __restrict__ pb
     }
 }
 
-// Several reductions over one group's planes in one sweep.
-struct FinalizeOuts {
-    int n;
-    int rtype[PCR_HIP_MAX_FINALIZE_OUTPUTS];
-    float* out[PCR_HIP_MAX_FINALIZE_OUTPUTS];
-};
-
-__device__ __forceinline__ float finalize_rt(int rt, float s, float w, float mx, float mn) {
-    switch (rt) {
-        case PCR_HIP_SUM: return s;
-        case PCR_HIP_COUNT: return w > 0.0f ? w : NAN;
-        case PCR_HIP_MAX: return mx == -FLT_MAX ? NAN : mx;
-        case PCR_HIP_MIN: return mn == FLT_MAX ? NAN : mn;
-        default: return w > 0.0f ? s / w : NAN;
-    }
-}
+// Several reductions over one group's planes in one sweep (FinalizeOuts, finalize_rt: common.hpp).
 
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_finalize_group(GridDev g, PlanesDev pl, unsigned need, const uint32_t* __restrict__ touched, FinalizeOuts fo) {
+k_finalize_group(GridDev g, PlanesDev pl, unsigned need, const uint32_t* __restrict__ touched, FinalizeOuts fo,
+                 const uint32_t* __restrict__ bands_done) {
+    if (bands_done && *bands_done != 0u) return;              // the scatter that defined the planes stored the bands as well
     const int rows = g.own_r1 - g.own_r0;
     const int per_row = g.W / VEC;
     const int64_t items = (int64_t)rows * per_row;
@@ -337,6 +324,12 @@ int pcr_hip_filter_mask(const pcr_hip_predicate* preds, int n_pred, uint64_t n, 
 
 int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
                            int n_out, const int* rtypes, float* const* d_outs, pcr_hip_stream s) {
+    return pcr_hip_finalize_group_unless(g, planes, d_tile_touched, n_out, rtypes, d_outs, nullptr, s);
+}
+
+int pcr_hip_finalize_group_unless(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
+                                  int n_out, const int* rtypes, float* const* d_outs, const uint32_t* d_bands_done,
+                                  pcr_hip_stream s) {
     int rc = validate_grid(g);
     if (rc) return rc;
     PCR_REQUIRE(planes && rtypes && d_outs, "finalize_group: null argument");
@@ -371,10 +364,10 @@ int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, 
     hipStream_t st = static_cast<hipStream_t>(s);
     if (aligned) {
         hipLaunchKernelGGL(k_finalize_group<4>, dim3(grid_for((int64_t)rows * (gd.W / 4))), dim3(kBlock), 0, st,
-                           gd, pl, need, d_tile_touched, fo);
+                           gd, pl, need, d_tile_touched, fo, d_bands_done);
     } else {
         hipLaunchKernelGGL(k_finalize_group<1>, dim3(grid_for((int64_t)rows * gd.W)), dim3(kBlock), 0, st,
-                           gd, pl, need, d_tile_touched, fo);
+                           gd, pl, need, d_tile_touched, fo, d_bands_done);
     }
     PCR_HIP_TRY(hipGetLastError());
     return PCR_HIP_OK;

@@ -146,7 +146,9 @@ public:
     void profile_enable(bool on, const std::string& only_kernel = "");   // only_kernel: bracket just that kernel with events
     std::vector<KernelTime> profile_read(bool reset);
     // path and LDS tiling the last scatter used (0 direct, 1 binned), exact valid-point count
-    struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; int scatter_chunk; };
+    // bands_with_scatter: accumulation groups whose finished bands the scatter that defined their planes was asked to store
+    // too and that nothing has invalidated since (finalize skips their kernel when the device confirms)
+    struct ScatterInfo { int path; int lds_tile_w, lds_tile_h, lds_apron, num_bins; size_t points_in, points_valid; int scatter_chunk; int bands_with_scatter; };
     ScatterInfo last_scatter() const;
 
     /// True when the grid's state did not fit the device budget and the pipeline sweeps it in row bands (out of core).

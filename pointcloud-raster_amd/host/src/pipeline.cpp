@@ -89,6 +89,9 @@ struct Pipeline::Impl {
         bool defined = false;            // the planes hold values (identity or accumulated).  They are NOT filled at create:
                                          // the first scatter defines them inside ingest, as the reference initialises its tile
                                          // state inside ingest (pipeline.cpp:688-691) -- see define_planes()
+        bool bands_with_scatter = false; // the scatter that defined the planes was asked to store this group's finished bands
+                                         // too (pcr_hip_engine_finalize_with_scatter) and nothing has touched the planes or the
+                                         // touched flags since: finalize() skips the group's kernel when the device agrees
     };
     struct Output {                      // one ReductionSpec -> one band
         int group = 0;
@@ -105,6 +108,8 @@ struct Pipeline::Impl {
     std::vector<Group> groups;
     std::vector<Output> outputs;
     std::vector<detail::Buffer> d_bands;     // finalized bands on the device (result_location == Host)
+    detail::Buffer d_bands_done;             // one device word per group: set by a scatter that stored the group's bands
+    bool state_shared = false;               // plane / touched-flag pointers have left the pipeline: never finalize with a scatter
     std::unique_ptr<Grid> result;
     bool finalized = false;                  // result() is null until the first finalize, as in the reference
     std::map<std::string, detail::Buffer> staging;   // device copies of host-resident arrays, grow-only
@@ -123,6 +128,32 @@ struct Pipeline::Impl {
     }
 
     int own_rows() const { return hg.own_row1 - hg.own_row0; }
+
+    // Bands a scatter may have stored are stale as soon as anything else writes the planes or the touched flags.
+    void bands_stale() { for (auto& gr : groups) gr.bands_with_scatter = false; }
+    float* band_device(size_t r) {
+        return cfg.result_location == MemoryLocation::Device ? result->band_f32((int)r) : static_cast<float*>(d_bands[r].data());
+    }
+    // The first Point scatter of a group defines its planes; when this device owns the whole state window (no halo) and
+    // nobody outside holds pointers into the state, that scatter's tile pass is asked to store the group's finished bands too
+    // -- finalize after a pipeline's only ingest then has nothing to read back (reference: finalize_result re-reads every
+    // tile's state, src/engine/pipeline.cpp:1154-1286).
+    bool offer_bands(size_t gi) {
+        const Group& gr = groups[gi];
+        if (gr.defined || gr.glyph.type != GlyphType::Point || state_shared || !result || !d_bands_done.data()) return false;
+        if (hg.own_row0 != hg.state_row0 || own_rows() != hg.state_rows || own_rows() <= 0) return false;
+        int types[PCR_HIP_MAX_FINALIZE_OUTPUTS];
+        float* dsts[PCR_HIP_MAX_FINALIZE_OUTPUTS];
+        int n = 0;
+        for (size_t r = 0; r < outputs.size(); ++r) {
+            if (outputs[r].group != (int)gi) continue;
+            if (n == PCR_HIP_MAX_FINALIZE_OUTPUTS) return false;
+            types[n] = static_cast<int>(outputs[r].type);
+            dsts[n++] = band_device(r);
+        }
+        if (n == 0) return false;
+        return pcr_hip_engine_finalize_with_scatter(engine, n, types, dsts, static_cast<uint32_t*>(d_bands_done.data()) + gi) == PCR_HIP_OK;
+    }
 
     Status init() {
         const GridConfig& g = cfg.grid;
@@ -270,6 +301,7 @@ struct Pipeline::Impl {
             gr.view.d_min = static_cast<float*>(gr.planes[3].data());
         }
         if (!outputs.empty() && !(s = allocate_result()).ok()) return s;
+        if (!(s = d_bands_done.allocate(std::max<size_t>(groups.size(), 1) * sizeof(uint32_t), MemoryLocation::Device)).ok()) return s;
         return detail::hip_status(pcr_hip_stream_synchronize(stream));
     }
 
@@ -514,7 +546,9 @@ struct Pipeline::Impl {
         }
         if (reach_needed > halo) return reach_error(reach_needed);
 
-        for (auto& gr : groups) {
+        bands_stale();                                   // (this cloud's points change the planes and the touched flags)
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            Group& gr = groups[gi];
             const void* dv = nullptr;
             s = f32_channel(gr.value_channel, &dv);
             if (!s.ok()) return s;
@@ -523,9 +557,11 @@ struct Pipeline::Impl {
             pcr_hip_engine_planes_fresh(engine, !gr.defined ? 2 : (gr.fresh && gr.glyph.type == GlyphType::Point ? 1 : 0));
             if (gr.glyph.type == GlyphType::Point) {
                 gr.fresh = false;
+                const bool offered = offer_bands(gi);
                 s = detail::hip_status(pcr_hip_scatter_point(
                     engine, gr.mask, &gr.view, static_cast<const double*>(dx), static_cast<const double*>(dy),
                     static_cast<const float*>(dv), n));
+                gr.bands_with_scatter = offered && s.ok() && pcr_hip_engine_finalize_taken(engine) == 1;
             } else {
                 pcr_hip_glyph hgph{};
                 hgph.type = static_cast<int32_t>(gr.glyph.type);
@@ -626,8 +662,10 @@ struct Pipeline::Impl {
             std::vector<size_t> bands_of;
             auto flush = [&]() -> Status {
                 if (types.empty()) return Status::success();
-                Status fs = detail::hip_status(pcr_hip_finalize_group(&hg, &groups[gi].view, d_touched, (int)types.size(),
-                                                                      types.data(), dsts.data(), stream));
+                // (a group whose bands the defining scatter stored: the kernel returns at once when the device word says so)
+                const uint32_t* done = groups[gi].bands_with_scatter ? static_cast<const uint32_t*>(d_bands_done.data()) + gi : nullptr;
+                Status fs = detail::hip_status(pcr_hip_finalize_group_unless(&hg, &groups[gi].view, d_touched, (int)types.size(),
+                                                                             types.data(), dsts.data(), done, stream));
                 types.clear();
                 dsts.clear();
                 return fs;
@@ -635,7 +673,7 @@ struct Pipeline::Impl {
             for (size_t r = 0; r < outputs.size(); ++r) {
                 if (outputs[r].group != (int)gi) continue;
                 types.push_back(static_cast<int>(outputs[r].type));
-                dsts.push_back(on_device ? result->band_f32((int)r) : static_cast<float*>(d_bands[r].data()));
+                dsts.push_back(band_device(r));
                 bands_of.push_back(r);
                 if (types.size() == PCR_HIP_MAX_FINALIZE_OUTPUTS && !(s = flush()).ok()) return s;
             }
@@ -745,6 +783,7 @@ struct Pipeline::Impl {
         return detail::hip_status(pcr_hip_stream_synchronize(stream));
     }
     Status import_window(const std::vector<std::vector<float>>& planes, const std::vector<uint32_t>& touched) {
+        bands_stale();
         DeviceScope dev(cfg.cuda_device_id);
         const size_t cells = (size_t)hg.state_rows * hg.width;
         if (planes.size() != groups.size() * 4)
@@ -812,6 +851,7 @@ struct Pipeline::Impl {
     }
 
     Status load_state(const std::string& dir_in) {
+        bands_stale();
         std::string dir;
         Status s = checkpoint_dir(dir_in, &dir);
         if (!s.ok()) return s;
@@ -1268,6 +1308,8 @@ std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
         (void)impl_->define_all_planes();               // the caller reads (and may write) them: identity where nothing was ingested
     }
     for (auto& g : impl_->groups) g.fresh = false;      // mutable pointers leave the pipeline: assume the planes get written
+    impl_->state_shared = true;
+    impl_->bands_stale();
     for (size_t g = 0; g < impl_->groups.size(); ++g)
         for (int p = 0; p < 4; ++p)
             if (impl_->groups[g].mask & kPlaneBits[p])
@@ -1281,6 +1323,8 @@ void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
     uint32_t* d = nullptr;
     int32_t tx = 0, ty = 0;
     if (pcr_hip_engine_tile_touched(impl_->engine, &d, &tx, &ty) != PCR_HIP_OK) return nullptr;
+    impl_->state_shared = true;                         // (the flags may be written from outside: the shard exchange does)
+    impl_->bands_stale();
     if (tiles_x) *tiles_x = tx;
     if (tiles_y) *tiles_y = ty;
     return d;
@@ -1318,8 +1362,10 @@ Pipeline::ScatterInfo Pipeline::last_scatter() const {
     if (banded_) return banded_->last;
     pcr_hip_scatter_stats st{};
     pcr_hip_engine_stats(impl_->engine, &st);
+    int fused = 0;
+    for (const auto& g : impl_->groups) fused += g.bands_with_scatter ? 1 : 0;
     return {st.path, st.lds_tile_w, st.lds_tile_h, st.lds_apron, st.num_bins,
-            (size_t)st.points_in, (size_t)st.points_valid, st.scatter_chunk};
+            (size_t)st.points_in, (size_t)st.points_valid, st.scatter_chunk, fused};
 }
 
 }  // namespace pcr

@@ -180,6 +180,7 @@ void bind_engine(py::module_& m) {
             d["points_in"] = s.points_in;
             d["points_valid"] = s.points_valid;
             d["scatter_chunk"] = s.scatter_chunk;
+            d["bands_with_scatter"] = s.bands_with_scatter;
             return d;
         })
         .def("out_of_core", &Pipeline::out_of_core,

@@ -120,10 +120,13 @@ SYMBOLS = {
     "pcr_hip_plane_merge": [_U32, _VP, _VP, _I64, _VP],
     "pcr_hip_finalize": [C.c_int, C.POINTER(Grid), C.POINTER(Planes), _VP, _VP, _VP],
     "pcr_hip_finalize_group": [C.POINTER(Grid), C.POINTER(Planes), _VP, C.c_int, C.POINTER(C.c_int), C.POINTER(_VP), _VP],
+    "pcr_hip_finalize_group_unless": [C.POINTER(Grid), C.POINTER(Planes), _VP, C.c_int, C.POINTER(C.c_int), C.POINTER(_VP), _VP, _VP],
     "pcr_hip_engine_create": [C.POINTER(_VP), C.POINTER(Grid), _SZ, _VP],
     "pcr_hip_engine_destroy": [_VP],
     "pcr_hip_engine_set_path": [_VP, C.c_int],
     "pcr_hip_engine_planes_fresh": [_VP, C.c_int],
+    "pcr_hip_engine_finalize_with_scatter": [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(_VP), _VP],
+    "pcr_hip_engine_finalize_taken": [_VP],
     "pcr_hip_engine_stats": [_VP, C.POINTER(ScatterStats)],
     "pcr_hip_engine_tile_touched": [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "pcr_hip_filter_mask": [C.POINTER(Predicate), C.c_int, _U64, _VP, _VP, _VP],
