@@ -510,15 +510,17 @@ def main():
             extra["exchange_ms"] = round(sp.exchange_ms, 4)
         extra["_warm"] = {k: round(v[1], 4) for k, v in sorted(warm.items())}
         if WORKLOADS[wl][1] == "line" and "k_tile_line" in warm:
-            # "achieved LDS-atomic ops/s next to the HBM fraction".  Every cell a segment visits is one
-            # ds_add_f64 (value) + one ds_add_u32 (weight 1) lane-operation in the tile's LDS window; the visits are the
-            # weight plane's total (exact: integers in f32 below 2^24 per cell), read after the timed steps
+            # "achieved LDS-atomic ops/s next to the HBM fraction".  Every cell a segment visits is ONE
+            # ds_add_u64 lane-operation in the tile's LDS window (k_tile_line_rec: visit count and fixed-point value share a
+            # 64-bit word when both planes are wanted; round 3 issued one atomic per plane); the visits are the weight
+            # plane's total (exact: integers in f32 below 2^24 per cell), read after the timed steps
             try:
                 visits = sum(float(t.double().sum().item()) for t, kind in sp._plane_tensors() if kind == 2)
                 nplanes = len(sp._plane_tensors())
                 ms_line = warm["k_tile_line"][1] / max(warm["k_tile_line"][0], 1)
-                extra["lds_atomic_lane_ops"] = visits * nplanes
-                extra["lds_atomic_lane_ops_per_s"] = visits * nplanes / (ms_line * 1e-3)
+                extra["lds_atomic_lane_ops"] = visits
+                extra["lds_atomic_lane_ops_per_s"] = visits / (ms_line * 1e-3)
+                extra["lds_plane_updates_per_s"] = visits * nplanes / (ms_line * 1e-3)
             except Exception as exc:
                 extra["lds_atomic_lane_ops_per_s"] = repr(exc)
         del pipes
@@ -782,7 +784,8 @@ def main():
                     "step_roofline_frac": round(step_bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "kernels_ms_per_step": warm2,
                     **({"lds_atomic_lane_ops_per_s": x2["lds_atomic_lane_ops_per_s"],
-                        "lds_atomic_lane_ops_per_step": x2["lds_atomic_lane_ops"]} if "lds_atomic_lane_ops" in x2 else {}),
+                        "lds_atomic_lane_ops_per_step": x2["lds_atomic_lane_ops"],
+                        "lds_plane_updates_per_s": x2["lds_plane_updates_per_s"]} if "lds_atomic_lane_ops" in x2 else {}),
                     **({"exchange": x2} if world > 1 else {})}
         if rank == 0:
             out["per_glyph"] = per_glyph
