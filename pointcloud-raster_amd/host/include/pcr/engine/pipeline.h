@@ -108,6 +108,11 @@ public:
     /// k+1 overlaps the host-to-device copy and the kernels of chunk k.  `points_read` (optional) = rows read.
     Status ingest_file(const std::string& path, size_t chunk_points = 4u << 20, size_t* points_read = nullptr);
     Status finalize();
+    /// Extension, the counterpart of ingest_async: with a device-resident result (result_location = Device, no output_path)
+    /// the finalize kernels are only ENQUEUED on the pipeline's stream -- result() is valid at once, its bands are complete
+    /// after synchronize() (or for anything ordered after it on stream_handle()).  Back-to-back pipelines then never leave
+    /// the device idle for a host round trip.  Any other configuration behaves as finalize().
+    Status finalize_async();
     Status run(const std::vector<const PointCloud*>& clouds);
     void set_progress_callback(ProgressCallback cb);
     const Grid* result() const;

@@ -637,7 +637,7 @@ struct Pipeline::Impl {
         return Status::success();
     }
 
-    Status finalize() {
+    Status finalize(bool wait = true) {
         const int rows = own_rows();
         const int W = hg.width;
         if (outputs.empty()) return Status::error(StatusCode::OutOfMemory, "pipeline: failed to allocate result grid");
@@ -686,8 +686,11 @@ struct Pipeline::Impl {
                 }
             }
         }
-        s = detail::hip_status(pcr_hip_stream_synchronize(stream));
-        if (!s.ok()) return s;
+        // finalize_async: a device-resident result is stream-ordered like everything else on the device
+        if (wait || !on_device || !cfg.output_path.empty()) {
+            s = detail::hip_status(pcr_hip_stream_synchronize(stream));
+            if (!s.ok()) return s;
+        }
         finalized = true;
         if (!cfg.output_path.empty()) {
             // pipeline.cpp:1351-1361 of the reference: the finalized grid goes to output_path as GeoTIFF.
@@ -1271,6 +1274,7 @@ Status Pipeline::ingest_file(const std::string& path, size_t chunk_points, size_
     return Status::success();
 }
 Status Pipeline::finalize() { return banded_ ? banded_->finalize() : impl_->finalize(); }
+Status Pipeline::finalize_async() { return banded_ ? banded_->finalize() : impl_->finalize(false); }
 
 Status Pipeline::run(const std::vector<const PointCloud*>& clouds) {
     for (const PointCloud* c : clouds) {

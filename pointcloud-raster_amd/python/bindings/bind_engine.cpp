@@ -128,6 +128,9 @@ void bind_engine(py::module_& m) {
         }, py::arg("path"), py::arg("chunk_points") = size_t(4) << 20,
              "stream a PCRP / CSV file through page-locked double buffers; returns the number of points read")
         .def("finalize", [](Pipeline& p) { raise_if_error(p.finalize()); })
+        .def("finalize_async", [](Pipeline& p) { raise_if_error(p.finalize_async()); },
+             "Device-resident result: the finalize kernels are only enqueued on the pipeline's stream (complete after synchronize()); "
+             "otherwise as finalize()")
         .def("run", [](Pipeline& p, const std::vector<const PointCloud*>& cs) { raise_if_error(p.run(cs)); })
         .def("set_progress_callback", &Pipeline::set_progress_callback)
         .def("result", &Pipeline::result, py::return_value_policy::reference_internal)

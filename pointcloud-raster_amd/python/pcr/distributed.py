@@ -463,9 +463,14 @@ class ShardedPipeline:
         p2p, _ = self.collectives_per_step()
         return (p2p // 2) * self.halo * self.width * 4
 
-    def finalize(self, timed=False):
+    def finalize(self, timed=False, wait=True):
+        """exchange + local finalize.  wait=False: Pipeline.finalize_async (a device-resident result is complete after
+        pipe.synchronize() / a device synchronisation)."""
         self.exchange(timed)
-        self.pipe.finalize()
+        if wait:
+            self.pipe.finalize()
+        else:
+            self.pipe.finalize_async()
 
     def result(self):
         return self.pipe.result()

@@ -194,3 +194,33 @@ def test_cabi_word_and_refusals():
             assert (outs[0].to_numpy(np.float32, (rows, W)).view(np.uint32) == 0x7F7F7F7F).all()
         finally:
             run.close()
+
+
+def test_finalize_async_leaves_stream_ordered_device_bands():
+    """Pipeline.finalize_async (extension): with a device-resident result the finalize kernels are only enqueued; the bands
+    are complete after synchronize().  Several pipelines back to back, as bench.py's timed steps run them; a host-resident
+    result makes the call an ordinary finalize."""
+    G, n = 1024, 300_000
+    rng = np.random.default_rng(13)
+    x, y = rng.uniform(2, G - 2, n), rng.uniform(2, 700, n)
+    v = rng.uniform(-1, 1, n).astype(np.float32)
+    og = O.make_grid((0, 0, G, G), tile=(256, 256))
+    cloud = cloud_from(x, y, {"value": v}, "device")
+    pipes = []
+    for _ in range(4):
+        cfg = config_for(og, [spec(t) for t in ALL6], scatter_path=2)
+        cfg.result_location = pcr.MemoryLocation.Device
+        p = pcr.Pipeline.create(cfg)
+        p.ingest(cloud)
+        p.ingest(cloud)                                            # (the second ingest: the ordinary finalize kernel, enqueued)
+        p.finalize_async()
+        assert p.result() is not None
+        pipes.append(p)
+    for p in pipes:
+        p.synchronize()
+        check_point_bands(OnHost(p), og, np.concatenate([x, x]), np.concatenate([y, y]), np.concatenate([v, v]), ALL6)
+    q = pcr.Pipeline.create(config_for(og, [spec("Count")], scatter_path=2))      # host-resident result
+    q.ingest(cloud)
+    q.finalize_async()
+    want = O.run(og, O.COUNT, x, y, v)
+    assert np.array_equal(bands(q)[0], want, equal_nan=True)
