@@ -56,7 +56,7 @@ constexpr int kCountThreads = 512;
 // block -> points mapping as k_bin_scatter's, because with nvx = 8 the counts are kept per virtual XCD (blockIdx % 8) and a
 // point must be counted under the virtual XCD that will store its record (see bin_points).  nvx = 1: one count per bin.
 __global__ void __launch_bounds__(kCountThreads)
-k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* __restrict__ x, const double* __restrict__ y,
+k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, const double* __restrict__ x, const double* __restrict__ y,
             uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
             uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
     extern __shared__ unsigned lds_hist[];
@@ -65,9 +65,14 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
     const bool one_tile = g.tiles_x * g.tiles_y == 1;
-    const bool tail = blockIdx.x >= full_blocks;
-    const uint64_t base = tail ? (uint64_t)full_blocks * b.chunk + (uint64_t)(blockIdx.x - full_blocks) * 4096 : (uint64_t)blockIdx.x * b.chunk;
-    const int len = tail ? 4096 : b.chunk;
+    // a scatter block's points are counted by `split` workgroups (all under the scatter block's virtual XCD): the count pass
+    // wants more, shorter workgroups than the scatter pass has chunks
+    const unsigned nsplit = full_blocks * (unsigned)split;
+    const bool tail = blockIdx.x >= nsplit;
+    const unsigned sblock = tail ? full_blocks + (blockIdx.x - nsplit) : blockIdx.x / (unsigned)split;      // the scatter pass's block
+    const int len = tail ? 4096 : b.chunk / split;
+    const uint64_t base = tail ? (uint64_t)full_blocks * b.chunk + (uint64_t)(blockIdx.x - nsplit) * 4096
+                               : (uint64_t)sblock * b.chunk + (uint64_t)(blockIdx.x % (unsigned)split) * len;
     unsigned my_valid = 0;
     // The routing is done once: pass B reads the 4-byte key written here instead of x, y (16 B).
     auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
@@ -83,7 +88,7 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
     const bool full = base + (uint64_t)len <= n &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (full) {
-        // 16-byte loads (two points per lane), four of them in flight per array before any math (len is a multiple of 4096)
+        // 16-byte loads (two points per lane), four of them in flight per array before any math (len is a multiple of 1024)
         const double2* x2 = reinterpret_cast<const double2*>(x + base);
         const double2* y2 = reinterpret_cast<const double2*>(y + base);
         uint2* k2 = reinterpret_cast<uint2*>(keys + base);
@@ -92,11 +97,13 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
             double2 xs[4], ys[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (p0 + u * kCountThreads >= pairs) break;               // (uniform over the workgroup)
                 xs[u] = stream_load(x2 + p0 + u * kCountThreads);
                 ys[u] = stream_load(y2 + p0 + u * kCountThreads);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (p0 + u * kCountThreads >= pairs) break;
                 const uint64_t i = base + 2ull * (p0 + u * kCountThreads);
                 unsigned ka = handle(i, xs[u].x, ys[u].x);
                 unsigned kb = handle(i + 1, xs[u].y, ys[u].y);
@@ -114,7 +121,7 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
     }
     if (my_valid) atomicAdd(&any_valid, my_valid);
     __syncthreads();
-    unsigned* mine = bin_count + (size_t)(blockIdx.x & (unsigned)(nvx - 1)) * b.nbins;
+    unsigned* mine = bin_count + (size_t)(sblock & (unsigned)(nvx - 1)) * b.nbins;
     for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) {
         unsigned c = lds_hist[i];
         if (c) atomicAdd(&mine[i], c);
@@ -133,6 +140,18 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int nvx, const double* _
 //   5504 bins (16384 x 4096, 250 M)  1.260   1.193   1.154   1.178   1.231
 // The single-level path now counts in the scatter pass's own blocks (28672 points: between the two best columns), because
 // the counts are kept per virtual XCD and both passes must see a point in the same block (bin_points).
+
+// Workgroups of the count pass per scatter block.  The scatter pass wants long chunks (28 672 points: its (block, bin) runs),
+// the count pass short ones: 1 744 workgroups of 512 threads are 2.3 rounds of the 768 a launch keeps resident, and the
+// third, quarter-full round runs as long as a full one.  Four workgroups per scatter block (7 168 points each, counted
+// under the scatter block's virtual XCD), A/B in one call on C2: k_bin_count 0.202 / 0.207 -> 0.182 / 0.186 ms, the step
+// 0.606 / 0.612 -> 0.591 / 0.592 (two: 0.194 / 0.180; seven: 0.208 / 0.213 -- every workgroup flushes its histogram with
+// up to nbins global atomics, so the split stops where that exceeds ~1/5 atomic per point).
+inline int count_split(int chunk, int nbins) {
+    int s = 4;
+    while (s > 1 && (chunk % s != 0 || (chunk / s) % 1024 != 0 || chunk / s < 5 * nbins)) s >>= 1;
+    return s;
+}
 
 // ---- scan: bin starts + work items ------------------------------------------------------------
 // A bin's records are split into items of at most item_records so that one hot bin cannot
@@ -753,9 +772,10 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         bc.chunk = kScatterChunk;
         const int full_blocks = scatter_full_blocks(v, n, kind == RecordKind::Index);
         const uint64_t done = (uint64_t)full_blocks * kScatterChunk;
-        const unsigned cblocks = (unsigned)full_blocks + (unsigned)((n - done + 4095) / 4096);
+        const int split = count_split(bc.chunk, b.nbins);
+        const unsigned cblocks = (unsigned)full_blocks * (unsigned)split + (unsigned)((n - done + 4095) / 4096);
         hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
-                           gd, bc, (unsigned)full_blocks, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+                           gd, bc, (unsigned)full_blocks, split, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
@@ -819,8 +839,10 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     PCR_HIP_TRY(hipMemsetAsync(U(o_count2), 0, (size_t)tiles.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        hipLaunchKernelGGL(k_bin_count, dim3(blocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
-                           e->gd, l1, (unsigned)full_blocks, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+        const int split = count_split(l1.chunk, l1.nbins);
+        const unsigned cblocks = (unsigned)full_blocks * (unsigned)split + (blocks - (unsigned)full_blocks);
+        hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
+                           e->gd, l1, (unsigned)full_blocks, split, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
