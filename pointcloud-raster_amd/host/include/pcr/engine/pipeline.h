@@ -80,6 +80,10 @@ struct PipelineConfig {
     // naming the rows needed) rather than clip silently -- raise this knob then.  Same value on every rank.
     int shard_halo_rows = -1;
     int scatter_path = 0;                            // 0 auto, 1 direct atomics, 2 binned LDS tiles, 3 moments+convolution (Gaussian)
+    // The first Point scatter of a pipeline also stores the finished bands (they are dropped again by any later ingest): the
+    // right default when finalize() follows a single ingest; pipelines that always ingest several clouds save one wasted band
+    // store by switching it off.
+    bool finalize_with_first_ingest = true;
 };
 
 struct ProgressInfo {

@@ -140,7 +140,8 @@ struct Pipeline::Impl {
     // tile's state, src/engine/pipeline.cpp:1154-1286).
     bool offer_bands(size_t gi) {
         const Group& gr = groups[gi];
-        if (gr.defined || gr.glyph.type != GlyphType::Point || state_shared || !result || !d_bands_done.data()) return false;
+        if (!cfg.finalize_with_first_ingest || gr.defined || gr.glyph.type != GlyphType::Point || state_shared || !result ||
+            !d_bands_done.data()) return false;
         if (hg.own_row0 != hg.state_row0 || own_rows() != hg.state_rows || own_rows() <= 0) return false;
         int types[PCR_HIP_MAX_FINALIZE_OUTPUTS];
         float* dsts[PCR_HIP_MAX_FINALIZE_OUTPUTS];
@@ -1070,6 +1071,7 @@ struct Pipeline::Banded {
         c.shard_row_begin = bands[b].first;
         c.shard_row_end = bands[b].second;
         c.result_location = MemoryLocation::Host;
+        c.finalize_with_first_ingest = false;             // (a band's visit ends with its state parked, never with finalize)
         c.output_path.clear();
         c.state_dir.clear();
         c.resume = false;

@@ -98,7 +98,8 @@ void bind_engine(py::module_& m) {
         .def_readwrite("shard_row_begin", &PipelineConfig::shard_row_begin)
         .def_readwrite("shard_row_end", &PipelineConfig::shard_row_end)
         .def_readwrite("shard_halo_rows", &PipelineConfig::shard_halo_rows)
-        .def_readwrite("scatter_path", &PipelineConfig::scatter_path);
+        .def_readwrite("scatter_path", &PipelineConfig::scatter_path)
+        .def_readwrite("finalize_with_first_ingest", &PipelineConfig::finalize_with_first_ingest);
 
     py::class_<ProgressInfo>(m, "ProgressInfo")
         .def(py::init<>())

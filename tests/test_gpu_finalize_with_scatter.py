@@ -70,6 +70,12 @@ def test_a_second_ingest_drops_the_stored_bands():
     assert p.last_scatter()["bands_with_scatter"] == 0
     p.finalize()
     check_point_bands(p, og, np.concatenate([x[:h], x2]), np.concatenate([y[:h], y2]), v, ALL6)
+    # PipelineConfig.finalize_with_first_ingest = False: never offered
+    q = pcr.Pipeline.create(config_for(og, [spec(t) for t in ALL6], scatter_path=2, finalize_with_first_ingest=False))
+    q.ingest(cloud_from(x, y, {"value": v}, "device"))
+    assert q.last_scatter()["bands_with_scatter"] == 0
+    q.finalize()
+    check_point_bands(q, og, x, y, v, ALL6)
 
 
 def test_planes_written_from_outside_drop_the_stored_bands():
@@ -97,6 +103,30 @@ def test_planes_written_from_outside_drop_the_stored_bands():
     assert q.last_scatter()["bands_with_scatter"] == 0
     q.finalize()
     assert np.allclose(bands(q)[0], want, rtol=1e-5, atol=1e-5)
+
+
+def test_touched_flags_written_from_outside_drop_the_stored_bands():
+    """The shard exchange ORs the other ranks' touched flags into this rank's (pcr.distributed.allreduce_touched, through
+    tile_touched_ptr()): a reference tile nobody touched here becomes 0.0 / NaN-per-cell instead of all NaN.  Bands stored by the
+    scatter were made from this rank's flags alone and must not survive."""
+    import torch
+    G, n = 1024, 40_000
+    x, y, v = sparse_cloud(G, n, 21)                                  # one corner: most of the sixteen reference tiles untouched
+    og = O.make_grid((0, 0, G, G), tile=(256, 256))
+    p = pcr.Pipeline.create(config_for(og, [spec("Sum"), spec("Count")], scatter_path=2))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    assert p.last_scatter()["bands_with_scatter"] == 1
+    ptr, tx, ty = p.tile_touched_ptr()
+    assert p.last_scatter()["bands_with_scatter"] == 0
+    flags = torch.as_tensor(pcr.DeviceArrayView(ptr, (ty * tx,), "<i4", owner=p), device="cuda")
+    flags.fill_(1)                                                   # "some other rank touched every tile"
+    torch.cuda.synchronize()
+    p.finalize()
+    sm, ct = bands(p)
+    want_s = np.nan_to_num(O.run(og, O.SUM, x, y, v, wide=True), nan=0.0)      # Q2: Sum of an empty cell of a touched tile = 0.0
+    assert not np.isnan(sm).any() and np.allclose(sm, want_s, rtol=1e-5, atol=1e-5)
+    want_c = O.run(og, O.COUNT, x, y, v)
+    assert np.array_equal(np.nan_to_num(ct), np.nan_to_num(want_c)) and np.isnan(ct).sum() == (np.nan_to_num(want_c) == 0).sum()
 
 
 def test_a_split_bin_leaves_the_bands_to_the_finalize_pass():
