@@ -118,3 +118,57 @@ def test_live_ref_glyph_quirk_probes(known_answers):
             assert band[row, col] == pytest.approx(val, rel=c["rtol"])
         if "cells_set" in c:
             assert sorted([int(r), int(cc)] for r, cc in np.argwhere(band != 0)) == sorted(c["cells_set"])
+
+
+def _random_glyph_case(seed):
+    """A random accumulate_glyph() call: grid origin / cell sizes / tile rectangle, glyph type and parameters, per-point channels
+    (with the values the reference special-cases: sigma <= 0, directions on the axes), every reduction a glyph takes."""
+    rng = np.random.default_rng(90000 + seed)
+    W, H = int(rng.integers(24, 120)), int(rng.integers(24, 120))
+    csx = float(rng.choice([0.25, 0.5, 1.0, 2.0, 3.0]))
+    csy = -float(rng.choice([0.25, 0.5, 1.0, 2.0, 3.0]))
+    x0, y1 = float(rng.choice([0.0, 100.0, -512.5, 1e5])), float(rng.choice([0.0, -50.0, 777.25, 1e5]))
+    grid = dict(bounds=(x0, y1 + H * csy, x0 + W * csx, y1), cell=(csx, csy), dims=(W, H))
+    if rng.uniform() < 0.5:
+        tile = dict(col0=0, row0=0, tw=W, th=H)
+    else:                                                     # an interior tile: footprints are clipped to it (Q4)
+        tw, th = int(rng.integers(8, W)), int(rng.integers(8, H))
+        tile = dict(col0=int(rng.integers(0, W - tw + 1)), row0=int(rng.integers(0, H - th + 1)), tw=tw, th=th)
+    case = dict(name=f"random_{seed}", grid=grid, tile=tile, n=int(rng.integers(50, 1500)), seed=int(rng.integers(1, 1 << 30)),
+                max_radius=float(rng.choice([2.0, 4.0, 7.5, 12.0, 32.0])))
+    if rng.uniform() < 0.5:
+        case["glyph"] = cases.GAUSSIAN
+        case["rtype"] = int(rng.choice([cases.SUM, cases.AVERAGE, cases.WEIGHTED_AVERAGE, cases.COUNT, cases.MAX, cases.MIN]))
+        case["sigma"] = (float(rng.uniform(0.3, 4.0)) * csx, float(rng.uniform(0.3, 4.0)) * abs(csy))
+        case["rotation"] = float(rng.choice([0.0, 0.0, rng.uniform(-3.2, 3.2)]))
+        names = [c for c in ("sigma_x", "sigma_y", "rotation") if rng.uniform() < 0.3]
+    else:
+        case["glyph"] = cases.LINE
+        case["rtype"] = int(rng.choice([cases.SUM, cases.WEIGHTED_AVERAGE, cases.COUNT, cases.AVERAGE, cases.MAX, cases.MIN]))
+        case["half_length"] = float(rng.uniform(0.3, 14.0)) * csx * float(rng.choice([1.0, 1.0, -1.0]))
+        case["direction"] = float(rng.uniform(-7.0, 7.0))
+        names = [c for c in ("direction", "half_length") if rng.uniform() < 0.5]
+        case["axis_dirs"] = bool(rng.uniform() < 0.2)
+    if names:
+        case["channels"] = tuple(names)
+    return case
+
+
+@pytest.mark.skipif(O.ref_lib() is None, reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("block", range(8))
+def test_live_ref_matches_oracle_on_random_glyph_cases(block):
+    """300 random accumulate_glyph() calls, the C restatement against the reference's own code: raw tile state and finalized
+    tile bit for bit (both fold the points in input order with the same fp32 operations)."""
+    R, L = O.ref_lib(), O.lib()
+    for seed in range(block * 40, block * 40 + 40):
+        case = _random_glyph_case(seed)
+        try:
+            st_r, fin_r = MRV.run_glyph(R.pcr_ref_accumulate_glyph, R.pcr_ref_init_state, R.pcr_ref_finalize_state, case)
+        except AssertionError:
+            # the reference refuses the combination (e.g. a reduction its glyph path does not take): the oracle must too
+            with pytest.raises(AssertionError):
+                MRV.run_glyph(L.pcro_accumulate_glyph, L.pcro_init_state, L.pcro_finalize_state, case)
+            continue
+        st_o, fin_o = MRV.run_glyph(L.pcro_accumulate_glyph, L.pcro_init_state, L.pcro_finalize_state, case)
+        _same(st_o, st_r, f"{case['name']} state ({case})")
+        _same(fin_o, fin_r, f"{case['name']} final ({case})")
