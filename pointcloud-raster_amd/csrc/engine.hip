@@ -418,9 +418,8 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
     gl.sigma_y = glyph->d_sigma_y;
     gl.rotation = glyph->d_rotation;
     DeviceGuard dev(e->device);
-    // glyph merges always accumulate (atomics, overlapping aprons): undefined planes are given their identity values first
-    if (e->planes_fresh == 2 && (rc = fill_identity(e, plane_mask, pl)) != PCR_HIP_OK) return rc;
-    e->planes_fresh = 0;
+    const bool undefined = e->planes_fresh == 2;
+    e->planes_fresh = 0;                                  // the hint covers one scatter
     rc = begin_scatter(e, n);
     if (rc) return rc;
     if (e->forced_path == 3 || e->forced_path == 0) {
@@ -428,11 +427,14 @@ int pcr_hip_scatter_glyph(pcr_hip_engine* e, const pcr_hip_glyph* glyph, uint32_
         if (e->forced_path == 3 && !can_mom && gl.type == PCR_HIP_GLYPH_GAUSSIAN)
             return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path forced but not applicable to this glyph");
         if (can_mom) {
-            rc = moments_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n);
+            // (undefined planes: the moment path's row pass stores every cell when one window covers the state window)
+            rc = moments_gauss(e, gl, plane_mask, pl, d_x, d_y, d_value, n, undefined);
             release_scratch(e);
             return rc;
         }
     }
+    // the tile merges accumulate (atomics, overlapping aprons): undefined planes are given their identity values first
+    if (undefined && (rc = fill_identity(e, plane_mask, pl)) != PCR_HIP_OK) return rc;
     bool can_bin = binned_glyph_supported(e, gl, plane_mask);
     if (e->forced_path == 2 && !can_bin)
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: binned path forced but not applicable");

@@ -146,7 +146,8 @@ int cells_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Plan
 
 // separable moment + convolution path for large default-sigma Gaussians, scatter_moments.hip
 bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask);
+// planes_undefined: the planes were only allocated (pcr_hip_engine_planes_fresh(e, 2)); the path defines every cell itself
 int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
-                  const double* x, const double* y, const float* v, uint64_t n);
+                  const double* x, const double* y, const float* v, uint64_t n, bool planes_undefined);
 
 }  // namespace pcrhip

@@ -548,7 +548,7 @@ k_conv_col_mfma(GridDev g, int K, int r, int yblocks_per_tile, const float* __re
 template <int LPR_SHIFT, int NPR>
 __global__ void __launch_bounds__(256)
 k_conv_row_accum(GridDev g, int K, int r, int xunits_per_tile, int rs, const float* __restrict__ taps_x,
-                 const float* __restrict__ u_in, int64_t plane_stride, float* __restrict__ out_plane) {
+                 const float* __restrict__ u_in, int64_t plane_stride, float* __restrict__ out_plane, int store) {
     constexpr int LPR = 1 << LPR_SHIFT, RW = 64 / LPR, COLS = 16 * LPR;
     extern __shared__ float lds_f[];
     const int lane = threadIdx.x & 63;
@@ -641,7 +641,10 @@ k_conv_row_accum(GridDev g, int K, int r, int xunits_per_tile, int rs, const flo
             const int gx = X0 + c;
             if (gx < t_hi) {
                 const float a = wt[row * rs + c + (c >> 4)];
-                if (a != 0.f) out_plane[(int64_t)gy * g.W + gx] += a;
+                // store: the plane is still UNDEFINED and this launch visits every cell of it once (one window = the whole
+                // state window): the row pass is the plane's initialisation, zeros included
+                if (store) out_plane[(int64_t)gy * g.W + gx] = a;
+                else if (a != 0.f) out_plane[(int64_t)gy * g.W + gx] += a;
             }
         }
     }
@@ -855,11 +858,19 @@ bool moments_supported(const pcr_hip_engine* e, const GlyphDev& gl, uint32_t mas
 }
 
 int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const PlanesDev& pl,
-                  const double* x, const double* y, const float* v, uint64_t n) {
+                  const double* x, const double* y, const float* v, uint64_t n, bool planes_undefined) {
     MomPlan p;
     std::vector<MomBand> bands;
     if (!make_plan(e->gd, gl, &p) || !plan_bands(e, p, &bands))
         return fail(PCR_HIP_INVALID_ARGUMENT, "scatter_glyph: moment path not applicable");
+    // Undefined planes (pcr_hip_engine_planes_fresh(e, 2)): when ONE window covers the whole state window, the row pass
+    // visits every cell of a plane exactly once and can store instead of accumulating -- the state initialisation costs no
+    // pass and no plane read; several windows add up in the state, which then has to hold its identity values first.
+    const bool store = planes_undefined && bands.size() == 1 && bands[0].win_r0 == 0 && bands[0].win_rows == e->gd.st_rows;
+    if (planes_undefined && !store) {
+        int frc = fill_identity(e, mask, pl);
+        if (frc) return frc;
+    }
     const int kinds = ((mask & 1) ? 1 : 0) + ((mask & 2) ? 1 : 0);
     const int tap_w = 2 * p.r + 1 + 2 * kPad;
     int max_rows = 0, max_bins = 0;
@@ -977,7 +988,8 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
         const dim3 row_grid(g.tiles_x * xunits, ((g.st_rows + rw - 1) / rw + 3) / 4);
         auto launch_row = [&](auto kernel, const float* src, float* outp) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
-            hipLaunchKernelGGL(kernel, row_grid, dim3(256), row_lds, e->stream, g, p.K, p.r, xunits, rs, taps_x, src, cells, outp);
+            hipLaunchKernelGGL(kernel, row_grid, dim3(256), row_lds, e->stream, g, p.K, p.r, xunits, rs, taps_x, src, cells, outp,
+                               store ? 1 : 0);
         };
         for (int kind = 0; kind < 2; ++kind) {
             const float* mom = kind == 0 ? mom_v : mom_w;
