@@ -207,8 +207,9 @@ int pcr_hip_engine_set_path(pcr_hip_engine* e, int path);
  *      or loaded since): the Point tile-merge stores instead of read-modify-writing (saves one read of the planes);
  *   2  they are UNDEFINED (never filled): the scatter itself leaves every cell of the state window defined -- the binned
  *      Point path by storing every cell of every LDS tile, identity included (no pass of its own; a bin the scan had to
- *      split, or a window swept in several bands / two sort levels, falls back to filling first), every other path by
- *      filling the planes with identity values before it accumulates (timed as `k_state_init`).
+ *      split, or a window swept in several bands / two sort levels, falls back to filling first), the moment path by
+ *      letting its row pass store instead of accumulate (one window over the whole state window; else it fills first),
+ *      every other path by filling the planes with identity values before it accumulates (timed as `k_state_init`).
  * The reference initialises tile state inside ingest, on first acquire (src/engine/tile_manager.cpp:272-320,
  * src/engine/pipeline.cpp:688-691): with 2 this build's state initialisation is inside the ingest as well. */
 int pcr_hip_engine_planes_fresh(pcr_hip_engine* e, int fresh);
