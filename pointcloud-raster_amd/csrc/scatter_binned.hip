@@ -138,15 +138,16 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
 //   1376 bins (C2, 50 M points)        0.228           0.267
 //   2816 bins (16384 x 2048, 125 M)  0.672   0.648   0.630   0.647   0.697
 //   5504 bins (16384 x 4096, 250 M)  1.260   1.193   1.154   1.178   1.231
-// The single-level path now counts in the scatter pass's own blocks (28672 points: between the two best columns), because
+// The single-level path now counts in the scatter pass's own blocks (scatter_shape: 12 288 or 16 384 points), because
 // the counts are kept per virtual XCD and both passes must see a point in the same block (bin_points).
 
-// Workgroups of the count pass per scatter block.  The scatter pass wants long chunks (28 672 points: its (block, bin) runs),
-// the count pass short ones: 1 744 workgroups of 512 threads are 2.3 rounds of the 768 a launch keeps resident, and the
-// third, quarter-full round runs as long as a full one.  Four workgroups per scatter block (7 168 points each, counted
-// under the scatter block's virtual XCD), A/B in one call on C2: k_bin_count 0.202 / 0.207 -> 0.182 / 0.186 ms, the step
-// 0.606 / 0.612 -> 0.591 / 0.592 (two: 0.194 / 0.180; seven: 0.208 / 0.213 -- every workgroup flushes its histogram with
-// up to nbins global atomics, so the split stops where that exceeds ~1/5 atomic per point).
+// Workgroups of the count pass per scatter block.  The scatter pass wants long chunks (its (block, bin) runs), the count pass
+// short ones: with round 2's 28 672-point chunks its 1 744 workgroups of 512 threads were 2.3 rounds of the 768 a launch keeps
+// resident, and the third, quarter-full round ran as long as a full one.  Four workgroups per scatter block (7 168 points
+// each, counted under the scatter block's virtual XCD), A/B in one call on C2: k_bin_count 0.202 / 0.207 -> 0.182 / 0.186 ms,
+// the step 0.606 / 0.612 -> 0.591 / 0.592 (two: 0.194 / 0.180; seven: 0.208 / 0.213 -- every workgroup flushes its histogram
+// with up to nbins global atomics, so the split stops where that exceeds ~1/5 atomic per point).  With today's chunks
+// (scatter_shape: 12 288 points at C2's 1 376 bins) the rule leaves one workgroup per block: 4 069 of them, 5.3 rounds.
 inline int count_split(int chunk, int nbins) {
     int s = 4;
     while (s > 1 && (chunk % s != 0 || (chunk / s) % 1024 != 0 || chunk / s < 5 * nbins)) s >>= 1;
@@ -231,7 +232,8 @@ k_bin_scan(int nbins, int nvx, unsigned item_records, const unsigned* __restrict
 // Shape = THREADS x PER points per workgroup, WINDOW records staged per round.  Measured on MI355X (50 M points;
 // tools/tune_scatter.sh, profiles/r02_tune_scatter.md): what pays is the LENGTH OF THE RUNS, i.e. the chunk --
 // every (block, bin) run is a partial-line write, and the 28672-point chunk that the 64 KB window makes possible
-// (1024 x 28, the most that stays under 128 VGPRs) beat the 16384-point chunk staged whole by 5 % at 1376 bins
+// (1024 x 28, the most that stays under 128 VGPRs) beat the 16384-point chunk staged whole by 5 % at 1376 bins [round 2's
+// measurement; round 4's, on today's kernels, is at scatter_shape below and says otherwise]
 // (C2), 27 % at 2816 bins (a C5 shard) and 35 % at 4096 bins (Gaussian index records).  Two 512-thread workgroups
 // per CU (same chunk, window 8192 or 4096) did NOT help: the load and write phases already run at the CU's
 // fair share of HBM, what is left is the sub-line write pattern itself.
@@ -390,31 +392,51 @@ k_bin_scatter(BinGeom b, unsigned full_blocks, int nvx, const unsigned* __restri
     }
 }
 
-// One launcher for both users (single-level binning and the first level of the two-level sort): 1024 threads x 28 points,
-// 64 KB staging window (the shape profiles/r02_tune_scatter.md settled on).
-constexpr int kScatterChunk = 1024 * 28;
+// Shape of the scatter pass: THREADS x PER points per workgroup (the chunk), WINDOW records staged per round.  Round 2
+// settled on 1024 x 28 with a 64 KB window (one workgroup per CU at the VGPR cap); round 4 measured the shapes again on the
+// kernels as they are now (A/B in one call, tools/ab_libs.sh; dominant-kernel ms of the timed steps / C2 step ms):
+//     1024 x 28, 8192   0.222-0.226 / 0.587-0.594        512 x 24, 8192    0.181-0.190 / 0.545-0.553   <- two workgroups per CU
+//     1024 x 24, 8192   0.189-0.194 / 0.564-0.567        512 x 20, 8192    0.181-0.186 / 0.551-0.553
+//     1024 x 16, 8192   0.193-0.199 / 0.555-0.568        512 x 16, 8192    0.187-0.188 / 0.558-0.562
+//     1024 x 16, 16384  0.190-0.194 / 0.557-0.558        512 x 32, 8192    0.220-0.223 / 0.592-0.602
+//     1024 x 12, 8192   0.235-0.239 / 0.604-0.611        512 x 32, 4096    0.265-0.270 / 0.632-0.634
+// and on a C5 shard (16384 x 2048, 2 816 bins, 125 M points; step ms): 1024 x 28: 1.495, 512 x 24: 1.553 (runs of four
+// records), 1024 x 16 with a 16384-record window: 1.428.  So: few bins -> two 512-thread workgroups per CU, whose phases
+// overlap; more bins -> the longer chunk of one 1024-thread workgroup, staged in ONE round while the LDS has the room.
+struct ScatterShape {
+    int threads, per, window;
+    int chunk() const { return threads * per; }
+};
+inline ScatterShape scatter_shape(int nbins) {
+    if (nbins <= 2048) return {512, 24, 8192};
+    if (nbins <= 4032) return {1024, 16, 16384};            // 128 KB + 8 B per bin (+ the static words) = the whole LDS
+    return {1024, 16, 8192};
+}
 constexpr int kVirtualXcds = 8;                    // record sub-ranges per bin (bin_points)
-// full 28672-point chunks of the scatter pass (the rest of the cloud goes in 4096-point blocks)
-inline int scatter_full_blocks(const float* v, uint64_t n, bool index) {
+// full chunks of the scatter pass (the rest of the cloud goes in 4096-point blocks)
+inline int scatter_full_blocks(const ScatterShape& sh, const float* v, uint64_t n, bool index) {
     const bool aligned = index || (reinterpret_cast<uintptr_t>(v) & 15) == 0;     // the keys are 256-B aligned
-    return aligned ? (int)(n / kScatterChunk) : 0;
+    return aligned ? (int)(n / (uint64_t)sh.chunk()) : 0;
 }
 
 template <bool INDEX>
 void launch_bin_scatter(pcr_hip_engine* e, const BinGeom& b, int nvx, const unsigned* d_keys, const float* v, uint64_t n,
                         unsigned* d_cursor, uint2* d_rec) {
-    constexpr int kT = 1024, kPer = 28, kWindow = 8192;
-    const uint64_t chunk = (uint64_t)kT * kPer;
-    static_assert(kT * kPer == kScatterChunk, "chunk");
-    const int full_blocks = scatter_full_blocks(v, n, INDEX);
-    const size_t lds = (size_t)kWindow * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
+    const ScatterShape sh = scatter_shape(b.nbins);
+    const uint64_t chunk = (uint64_t)sh.chunk();
+    const int full_blocks = scatter_full_blocks(sh, v, n, INDEX);
+    const size_t lds = (size_t)sh.window * sizeof(uint2) + (size_t)b.nbins * 4 * 2;
     const uint64_t done = (uint64_t)full_blocks * chunk;
     const unsigned tail_blocks = (unsigned)((n - done + 4095) / 4096);            // the chunk is a multiple of 4096
     ScopedKernelTimer t(e, "k_bin_scatter");
-    auto kernel = &k_bin_scatter<kT, kPer, kWindow, INDEX>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)full_blocks + tail_blocks), dim3(kT), lds, e->stream, b, (unsigned)full_blocks, nvx,
-                       d_keys, v, n, d_cursor, d_rec);
+    auto go = [&](auto kernel, int threads) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)full_blocks + tail_blocks), dim3(threads), lds, e->stream, b, (unsigned)full_blocks, nvx,
+                           d_keys, v, n, d_cursor, d_rec);
+    };
+    if (sh.threads == 512) go(&k_bin_scatter<512, 24, 8192, INDEX>, 512);
+    else if (sh.window == 16384) go(&k_bin_scatter<1024, 16, 16384, INDEX>, 1024);
+    else go(&k_bin_scatter<1024, 16, 8192, INDEX>, 1024);
     e->stats_scatter_chunk = (int)chunk;
 }
 
@@ -767,11 +789,12 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
     PCR_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)nvx * b.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        // the count pass walks the cloud in the scatter pass's blocks (28672 points, then 4096-point blocks for the ragged end)
+        // the count pass walks the cloud in the scatter pass's blocks (its chunks, then 4096-point blocks for the ragged end)
         BinGeom bc = b;
-        bc.chunk = kScatterChunk;
-        const int full_blocks = scatter_full_blocks(v, n, kind == RecordKind::Index);
-        const uint64_t done = (uint64_t)full_blocks * kScatterChunk;
+        const ScatterShape sh = scatter_shape(b.nbins);
+        bc.chunk = sh.chunk();
+        const int full_blocks = scatter_full_blocks(sh, v, n, kind == RecordKind::Index);
+        const uint64_t done = (uint64_t)full_blocks * sh.chunk();
         const int split = count_split(bc.chunk, b.nbins);
         const unsigned cblocks = (unsigned)full_blocks * (unsigned)split + (unsigned)((n - done + 4095) / 4096);
         hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
@@ -811,11 +834,12 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
                          uint64_t n, bool index_records, unsigned item_records, BinBuffers* out) {
     BinGeom l1 = tiles;                                                   // first level: groups of tiles
     l1.nbins = (tiles.nbins + (1 << tiles.sup_shift) - 1) >> tiles.sup_shift;
-    l1.chunk = kScatterChunk;                                             // the count pass walks the scatter pass's blocks (bin_points)
+    const ScatterShape sh1 = scatter_shape(l1.nbins);
+    l1.chunk = sh1.chunk();                                               // the count pass walks the scatter pass's blocks (bin_points)
     constexpr int nvx = kVirtualXcds;                                     // (measured neutral here: the first level's runs are ~170 records long)
     const unsigned sub_records = kSubPer * kThreads;
-    const int full_blocks = scatter_full_blocks(v, n, index_records);
-    const unsigned blocks = (unsigned)full_blocks + (unsigned)((n - (uint64_t)full_blocks * kScatterChunk + 4095) / 4096);
+    const int full_blocks = scatter_full_blocks(sh1, v, n, index_records);
+    const unsigned blocks = (unsigned)full_blocks + (unsigned)((n - (uint64_t)full_blocks * sh1.chunk() + 4095) / 4096);
     const int max_items1 = l1.nbins + (int)(n / sub_records) + 1;
     const int max_items2 = tiles.nbins + (int)(n / item_records) + 1;
 
