@@ -85,6 +85,9 @@ k_b16_count(GridDev g, BinGeom b, int cb, const double* __restrict__ x, const do
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
+    __shared__ unsigned lds_touch[kTouchLdsTiles];
+    TouchLds tl;
+    tl.begin(g, lds_touch, kCountThreads);
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
     const bool one_tile = g.tiles_x * g.tiles_y == 1;
@@ -98,7 +101,7 @@ k_b16_count(GridDev g, BinGeom b, int cb, const double* __restrict__ x, const do
         const Routed16 r = classify<CENTRE>(g, b, i, wx, wy, pg);
         if (r.kind == 0) return;
         ++my_valid;
-        if (!one_tile) touch_tile(g, touched, pg.row, pg.col);
+        if (!one_tile) tl.touch(g, touched, pg.row, pg.col);
         if (r.kind == 1) atomicAdd(&lds_hist[r.bin], 1u);
         else fb_list[atomicAdd(fb_count, 1u)] = (unsigned)i;
     };
@@ -141,6 +144,7 @@ k_b16_count(GridDev g, BinGeom b, int cb, const double* __restrict__ x, const do
         const unsigned c = lds_hist[i];
         if (c) atomicAdd(&mine[i], c);
     }
+    tl.flush(g, touched, kCountThreads);
     if (threadIdx.x == 0 && any_valid) {
         atomicAdd(counters, (unsigned long long)any_valid);
         if (one_tile) touched[0] = 1u;

@@ -195,6 +195,34 @@ __device__ __forceinline__ void touch_tile(const GridDev& g, uint32_t* touched, 
         __hip_atomic_store(touched + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same for a whole workgroup of a counting pass: on a grid of up to kTouchLdsTiles reference tiles the flags are first
+// gathered in LDS (plain stores, every writer stores 1) and only the tiles the workgroup saw are flagged in memory at its end
+// -- one L2 round trip per (workgroup, tile) instead of one per POINT (the agent-scope load above is never served by the L1:
+// on a C5 shard, four tiles, it was a dependent L2 access for each of the 125 M points of the count pass).
+constexpr int kTouchLdsTiles = 1024;
+struct TouchLds {
+    unsigned* flags;            // [kTouchLdsTiles] in LDS, zeroed by begin()
+    bool on;                    // false: one tile (the caller flags it itself) or too many tiles (touch_tile per point)
+    __device__ __forceinline__ void begin(const GridDev& g, unsigned* lds, int threads) {
+        flags = lds;
+        const int nt = g.tiles_x * g.tiles_y;
+        on = nt > 1 && nt <= kTouchLdsTiles;
+        if (on) for (int i = threadIdx.x; i < nt; i += threads) flags[i] = 0u;
+    }
+    __device__ __forceinline__ void touch(const GridDev& g, uint32_t* touched, int row, int col) const {
+        if (on) flags[fast_div(row, g.th) * g.tiles_x + fast_div(col, g.tw)] = 1u;
+        else touch_tile(g, touched, row, col);
+    }
+    // after a barrier that orders the workgroup's touch() calls
+    __device__ __forceinline__ void flush(const GridDev& g, uint32_t* touched, int threads) const {
+        if (!on) return;
+        const int nt = g.tiles_x * g.tiles_y;
+        for (int i = threadIdx.x; i < nt; i += threads)
+            if (flags[i] && __hip_atomic_load(touched + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                __hip_atomic_store(touched + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 #endif  // __HIPCC__
 
 }  // namespace pcrhip

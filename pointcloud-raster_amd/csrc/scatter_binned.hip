@@ -62,6 +62,9 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
+    __shared__ unsigned lds_touch[kTouchLdsTiles];
+    TouchLds tl;
+    tl.begin(g, lds_touch, kCountThreads);
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
     const bool one_tile = g.tiles_x * g.tiles_y == 1;
@@ -80,7 +83,7 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
         if (r.valid && point_kept(g, i)) {
             atomicAdd(&lds_hist[r.bin >> b.sup_shift], 1u);
             ++my_valid;
-            if (!one_tile) touch_tile(g, touched, r.row, r.col);
+            if (!one_tile) tl.touch(g, touched, r.row, r.col);
             return ((unsigned)r.bin << kLcellBits) | r.lcell;
         }
         return 0xFFFFFFFFu;
@@ -126,6 +129,7 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
         unsigned c = lds_hist[i];
         if (c) atomicAdd(&mine[i], c);
     }
+    tl.flush(g, touched, kCountThreads);
     if (threadIdx.x == 0 && any_valid) {
         atomicAdd(counters, (unsigned long long)any_valid);
         if (one_tile) touched[0] = 1u;
