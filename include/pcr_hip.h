@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define PCR_HIP_ABI_VERSION 4   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2;
-                                 * 4: + engine_finalize_with_scatter / engine_finalize_taken / finalize_group_unless */
+                                 * 4: + engine_finalize_with_scatter / engine_finalize_taken / finalize_group_unless / touched_union */
 
 typedef enum pcr_hip_status {
     PCR_HIP_OK = 0,
@@ -180,6 +180,13 @@ int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, 
 int pcr_hip_finalize_group_unless(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
                                   int n_out, const int* rtypes, float* const* d_outs, const uint32_t* d_bands_done,
                                   pcr_hip_stream s);
+
+/* Union of another rank's touched-tile flags into this device's (row-block shards: a reference tile is touched if ANY rank saw
+ * a point in it).  d_local[i] |= d_union[i] != 0, i < n; when that changed a flag, the n_words device words at d_bands_done
+ * (may be NULL) are zeroed: bands that a scatter stored from the local flags alone are then stale and the finalize pass runs
+ * (pcr_hip_finalize_group_unless).  Unchanged flags leave them alone -- the usual case on dense clouds. */
+int pcr_hip_touched_union(uint32_t* d_local, const uint32_t* d_union, int32_t n, uint32_t* d_bands_done, int32_t n_words,
+                          pcr_hip_stream s);
 
 /* ---- scatter engine.  replaces: TileRouter::assign + sort + extract_batches
  *      (include/pcr/engine/tile_router_kernels.h:15-52, src/engine/tile_router.cpp:51-366),

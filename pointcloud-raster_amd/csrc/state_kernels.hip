@@ -322,6 +322,30 @@ int pcr_hip_filter_mask(const pcr_hip_predicate* preds, int n_pred, uint64_t n, 
     return PCR_HIP_OK;
 }
 
+namespace {
+__global__ void __launch_bounds__(256)
+k_touched_union(uint32_t* __restrict__ local, const uint32_t* __restrict__ other, int n, uint32_t* __restrict__ done, int n_words) {
+    __shared__ unsigned changed;
+    if (threadIdx.x == 0) changed = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (other[i] != 0u && local[i] == 0u) { local[i] = 1u; changed = 1u; }      // (every writer stores 1)
+    __syncthreads();
+    if (changed && done)
+        for (int w = threadIdx.x; w < n_words; w += 256) done[w] = 0u;
+}
+}  // namespace
+
+int pcr_hip_touched_union(uint32_t* d_local, const uint32_t* d_union, int32_t n, uint32_t* d_bands_done, int32_t n_words,
+                          pcr_hip_stream s) {
+    PCR_REQUIRE(d_local && d_union && n >= 0 && n_words >= 0, "touched_union: bad argument");
+    if (n == 0) return PCR_HIP_OK;
+    hipLaunchKernelGGL(k_touched_union, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d_local, d_union, (int)n,
+                       d_bands_done, (int)n_words);
+    PCR_HIP_TRY(hipGetLastError());
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_finalize_group(const pcr_hip_grid* g, const pcr_hip_planes* planes, const uint32_t* d_tile_touched,
                            int n_out, const int* rtypes, float* const* d_outs, pcr_hip_stream s) {
     return pcr_hip_finalize_group_unless(g, planes, d_tile_touched, n_out, rtypes, d_outs, nullptr, s);

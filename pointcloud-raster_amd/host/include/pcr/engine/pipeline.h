@@ -148,6 +148,11 @@ public:
     int state_row_count() const;
     std::vector<PlaneView> state_planes() const;
     void* tile_touched_device(int* tiles_x, int* tiles_y) const;
+    /// The same flags for READING only (nothing is assumed to change: bands a scatter stored stay valid).
+    const void* tile_touched_device_readonly(int* tiles_x, int* tiles_y) const;
+    /// Row-block shards: ORs `d_union` (tiles_x * tiles_y device words: the all-reduced flags of every rank) into this
+    /// pipeline's flags on its stream; bands a scatter stored are dropped -- on the device -- only when a flag really changed.
+    Status merge_touched(const void* d_union);
     Status synchronize();
     void* stream_handle() const;                 // the hipStream_t every kernel of this pipeline runs on (may be null)
     // per-kernel HIP-event timing of the scatter kernels (roofline reporting)

@@ -1336,6 +1336,30 @@ void* Pipeline::tile_touched_device(int* tiles_x, int* tiles_y) const {
     return d;
 }
 
+const void* Pipeline::tile_touched_device_readonly(int* tiles_x, int* tiles_y) const {
+    if (banded_) return nullptr;
+    uint32_t* d = nullptr;
+    int32_t tx = 0, ty = 0;
+    if (pcr_hip_engine_tile_touched(impl_->engine, &d, &tx, &ty) != PCR_HIP_OK) return nullptr;
+    if (tiles_x) *tiles_x = tx;
+    if (tiles_y) *tiles_y = ty;
+    return d;
+}
+
+Status Pipeline::merge_touched(const void* d_union) {
+    if (banded_) return Status::error(StatusCode::NotImplemented, "pipeline: an out-of-core pipeline is not a shard");
+    if (!d_union) return Status::error(StatusCode::InvalidArgument, "pipeline: merge_touched: null flags");
+    Impl::DeviceScope dev(impl_->cfg.cuda_device_id);
+    uint32_t* d = nullptr;
+    int32_t tx = 0, ty = 0;
+    Status s = detail::hip_status(pcr_hip_engine_tile_touched(impl_->engine, &d, &tx, &ty));
+    if (!s.ok()) return s;
+    // (the stored bands' device words decide: the host keeps offering them to finalize, whose kernel runs when they are 0)
+    return detail::hip_status(pcr_hip_touched_union(d, static_cast<const uint32_t*>(d_union), tx * ty,
+                                                    static_cast<uint32_t*>(impl_->d_bands_done.data()),
+                                                    (int32_t)impl_->groups.size(), impl_->stream));
+}
+
 Status Pipeline::save_state(const std::string& dir) {
     if (banded_) return Status::error(StatusCode::NotImplemented, "pipeline: `.pcrt` checkpoints of an out-of-core pipeline are not supported");
     return impl_->save_state(dir);

@@ -160,11 +160,16 @@ void bind_engine(py::module_& m) {
             for (const auto& v : p.state_planes()) out.append(v.reach_rows);
             return out;
         })
-        .def("tile_touched_ptr", [](const Pipeline& p) {
+        .def("tile_touched_ptr", [](const Pipeline& p, bool readonly) {
             int tx = 0, ty = 0;
-            void* d = p.tile_touched_device(&tx, &ty);
+            const void* d = readonly ? p.tile_touched_device_readonly(&tx, &ty) : p.tile_touched_device(&tx, &ty);
             return py::make_tuple(reinterpret_cast<uintptr_t>(d), tx, ty);
-        })
+        }, py::arg("readonly") = false,
+             "(device pointer, tiles_x, tiles_y) of the touched-tile flags; readonly=True promises not to write them (bands a "
+             "scatter stored stay valid)")
+        .def("merge_touched", [](Pipeline& p, uintptr_t d_union) {
+            raise_if_error(p.merge_touched(reinterpret_cast<const void*>(d_union)));
+        }, "OR the all-reduced touched flags of every rank (device words) into this pipeline's flags, on its stream")
         .def("synchronize", [](Pipeline& p) { raise_if_error(p.synchronize()); })
         .def("stream_ptr", [](const Pipeline& p) { return reinterpret_cast<uintptr_t>(p.stream_handle()); })
         .def("profile_enable", &Pipeline::profile_enable, py::arg("on"), py::arg("only_kernel") = "")

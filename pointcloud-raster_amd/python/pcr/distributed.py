@@ -280,6 +280,8 @@ class ShardedPipeline:
         self._line_hl_groups = any(r.glyph.type == pcr.GlyphType.Line and r.glyph.half_length_channel
                                    for r in cfg.reductions)
         self._views = None
+        self._touched_ro = None
+        self._keep_union = None
         # Touched flags are per reference tile.  When every block edge falls on a tile-row boundary no tile is
         # shared between ranks and the flags are purely local: a Point-glyph run then needs no collective at all.
         th = cfg.grid.tile_height
@@ -394,6 +396,8 @@ class ShardedPipeline:
         # tile-aligned blocks nothing ever lands in a neighbour's rows -- no halo to reduce either
         if self.world == 1 or self.tiles_local:
             return
+        if self.halo == 0 and self._comm is None:
+            return self._exchange_flags_only(timed)
         planes = self._plane_tensors()
         if self._comm is not None:
             return self._exchange_native(planes, timed)
@@ -422,6 +426,37 @@ class ShardedPipeline:
         if timed:
             e1.synchronize()
             self.exchange_ms = e0.elapsed_time(e1)
+
+    def _exchange_flags_only(self, timed):
+        """A pipeline without glyph planes (halo 0) exchanges nothing but the touched-tile flags.  They are all-reduced in a COPY
+        and merged back by Pipeline.merge_touched: the pipeline's planes and flags are never handed out for writing, so the
+        bands its scatter may have stored stay valid unless another rank really touched a tile this one did not (decided on
+        the device: no host synchronisation)."""
+        import pcr
+        if self._touched_ro is None:
+            ptr, tx, ty = self.pipe.tile_touched_ptr(readonly=True)
+            self._touched_ro = torch.as_tensor(pcr.DeviceArrayView(ptr, (ty * tx,), "<i4", owner=self.pipe), device="cuda")
+        ptr = self.pipe.stream_ptr()
+        if ptr:
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(ptr))
+        else:
+            self.pipe.synchronize()
+            ctx = torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            union = self._touched_ro.clone()
+            allreduce_touched(union, self.group)
+            self.pipe.merge_touched(union.data_ptr())           # (on the pipeline's stream = this one, or after the sync below)
+            if timed:
+                e1.record()
+        if not ptr:
+            torch.cuda.current_stream().synchronize()
+        if timed:
+            e1.synchronize()
+            self.exchange_ms = e0.elapsed_time(e1)
+        self._keep_union = union                                # alive until the merge kernel has run (next exchange / finalize sync)
 
     def _exchange_native(self, planes, timed):
         """pcr_hip_comm_halo_reduce + pcr_hip_comm_allreduce_max_u32 on the engine's stream (no torch in the data path)."""

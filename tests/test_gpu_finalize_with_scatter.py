@@ -254,3 +254,36 @@ def test_finalize_async_leaves_stream_ordered_device_bands():
     q.finalize_async()
     want = O.run(og, O.COUNT, x, y, v)
     assert np.array_equal(bands(q)[0], want, equal_nan=True)
+
+
+def test_merge_touched_keeps_the_stored_bands_unless_a_flag_changes():
+    """Row-block shards without glyph planes all-reduce their touched flags in a copy and hand the union to
+    Pipeline.merge_touched: an unchanged union (the usual case) leaves the bands the scatter stored valid; a tile another rank
+    touched makes the device drop them and the finalize pass runs with the merged flags."""
+    import torch
+    G, n = 1024, 40_000
+    x, y, v = sparse_cloud(G, n, 33)
+    og = O.make_grid((0, 0, G, G), tile=(256, 256))
+    want_s = O.run(og, O.SUM, x, y, v, wide=True)
+    for other_rank_touches_more in (False, True):
+        p = pcr.Pipeline.create(config_for(og, [spec("Sum"), spec("Count")], scatter_path=2))
+        p.ingest(cloud_from(x, y, {"value": v}, "device"))
+        ptr, tx, ty = p.tile_touched_ptr(readonly=True)
+        assert p.last_scatter()["bands_with_scatter"] == 1               # reading the flags drops nothing
+        mine = torch.as_tensor(pcr.DeviceArrayView(ptr, (ty * tx,), "<i4", owner=p), device="cuda")
+        union = mine.clone()
+        if other_rank_touches_more:
+            union.fill_(1)
+        torch.cuda.synchronize()
+        p.merge_touched(union.data_ptr())
+        assert p.last_scatter()["bands_with_scatter"] == 1               # (the device decides)
+        p.finalize()
+        sm, ct = bands(p)
+        if other_rank_touches_more:
+            assert not np.isnan(sm).any() and np.allclose(sm, np.nan_to_num(want_s, nan=0.0), rtol=1e-5, atol=1e-5)
+            assert int(mine.sum().item()) == tx * ty
+        else:
+            assert np.array_equal(np.isnan(sm), np.isnan(want_s)) and np.isnan(sm).any()
+            m = ~np.isnan(want_s)
+            assert np.allclose(sm[m], want_s[m], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(np.nan_to_num(ct), np.nan_to_num(O.run(og, O.COUNT, x, y, v)))

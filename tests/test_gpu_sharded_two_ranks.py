@@ -85,3 +85,83 @@ def test_two_rank_sharded_pipeline_matches_oracle(tmp_path, tile_h):
         assert np.array_equal(np.isnan(got), np.isnan(w)), f"band {b}: NaN mask"
         m = ~np.isnan(w)
         assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"band {b}"
+
+
+def _point_inputs():
+    """Rank 0 (rows [0, 60)) sees points in tile row 0 (rows 0..63, every tile column); rank 1 (rows [60, 120)) only in tile
+    (1, 0) -- but it OWNS rows 60..63 of tile row 0, which its own flags leave untouched."""
+    rng = np.random.default_rng(5)
+    n0, n1 = 20000, 6000
+    x = np.concatenate([rng.uniform(0, G_W, n0), rng.uniform(0, 64, n1)])
+    y = np.concatenate([rng.uniform(G_H - 56, G_H, n0), rng.uniform(0, G_H - 70, n1)])      # north-up: row = G_H - y
+    v = rng.uniform(-1, 1, n0 + n1).astype(np.float32)
+    return x, y, v
+
+
+def _worker_points(rank, world, port, out_dir):
+    import torch                                   # before pcr: one shared HIP runtime
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+    import pcr
+    from pcr.distributed import ShardedPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, y, v = _point_inputs()
+        cfg = pcr.PipelineConfig()
+        cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G_W), float(G_H))
+        cfg.grid.tile_width, cfg.grid.tile_height = 64, 64
+        cfg.grid.compute_dimensions()
+        cfg.exec_mode = pcr.ExecutionMode.GPU
+        cfg.scatter_path = 2                        # binned: the scatter stores the bands, the exchange must drop them where needed
+        specs = []
+        for t in (pcr.ReductionType.Sum, pcr.ReductionType.Count, pcr.ReductionType.Max):
+            r = pcr.ReductionSpec()
+            r.value_channel, r.type = "value", t
+            specs.append(r)
+        cfg.reductions = specs
+        sp = ShardedPipeline(cfg, rank, world, device_id=0)
+        assert sp.halo == 0 and not sp.tiles_local
+        cloud = pcr.PointCloud.create(len(x))
+        cloud.set_x_array(x)
+        cloud.set_y_array(y)
+        cloud.add_channel("value", pcr.DataType.Float32)
+        cloud.set_channel_array_f32("value", v)
+        sp.ingest(cloud.to_device())
+        stored = sp.pipe.last_scatter()["bands_with_scatter"]
+        sp.finalize()
+        still = sp.pipe.last_scatter()["bands_with_scatter"]       # the flags-only exchange hands nothing out for writing
+        res = sp.result()
+        np.savez(os.path.join(out_dir, f"p{rank}.npz"), own=np.array(sp.own), stored=stored, still=still,
+                 **{f"b{i}": np.array(res.band_array(i)) for i in range(3)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_point_pipelines_exchange_flags_only(tmp_path):
+    """Point-only shards exchange nothing but the touched flags -- in a copy, merged back on the device -- and the bands the
+    scatter stored survive on the rank whose flags the union does not change (rank 0) and are redone on the other."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcr_oracle_py as O
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_points, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x, y, v = _point_inputs()
+    og = O.make_grid((0, 0, G_W, G_H), tile=(64, 64))
+    want = [O.run(og, O.SUM, x, y, v, wide=True), O.run(og, O.COUNT, x, y, v), O.run(og, O.MAX, x, y, v)]
+    parts = [np.load(tmp_path / f"p{r}.npz") for r in range(2)]
+    assert parts[0]["own"].tolist() == [0, 60] and parts[1]["own"].tolist() == [60, 120]
+    assert int(parts[0]["stored"]) == 1 and int(parts[1]["stored"]) == 1 and int(parts[0]["still"]) == 1
+    for b, (rt, at) in enumerate([(1e-5, 1e-6), (0, 0), (0, 0)]):
+        got = np.vstack([parts[0][f"b{b}"], parts[1][f"b{b}"]])
+        w = want[b]
+        assert np.array_equal(np.isnan(got), np.isnan(w)), f"band {b}: NaN mask"
+        m = ~np.isnan(w)
+        assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"band {b}"
+    # rows 60..63 of rank 1 lie in tile row 0, which only rank 0 touched: Sum there is 0.0, not NaN
+    assert not np.isnan(parts[1]["b0"][:4]).any() and (parts[1]["b0"][:4] == 0.0).all()
