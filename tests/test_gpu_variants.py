@@ -256,3 +256,34 @@ def test_line_tiles_packed_and_f64_forms_agree_with_the_oracle(A, spread):
     err = np.abs(got_s[occ] - exact[occ])
     # f32 merges of a few window partial sums per cell: a few ulp of the cell's own magnitude
     assert (err <= 4e-7 * np.maximum(mag[occ], 1e-30)).all(), f"{spread}: max rel err {np.max(err / np.maximum(mag[occ], 1e-30)):.3e}"
+
+
+@pytest.mark.parametrize("dims,shape", [((2048, 1024), "512x24 (<= 2048 bins)"), ((8192, 4096), "1024x16, one staging round (2752 bins)"),
+                                        ((8192, 8192), "1024x16, 8192-record window (5504 bins)")],
+                         ids=["few_bins", "mid_bins", "many_bins"])
+def test_point_scatter_shapes_by_bin_count(A, dims, shape):
+    """The Point scatter pass picks its workgroup shape from the number of LDS tiles (scatter_shape, scatter_binned.hip): one
+    case per shape, with a ragged end of the cloud (n is no multiple of any chunk) -- Count bit-exact, Sum and Max against the
+    oracle."""
+    W, H = dims
+    n = 3_000_017
+    rng = np.random.default_rng(W + H)
+    x, y = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    v = rng.uniform(-1, 1, n).astype(np.float32)
+    og = O.make_grid((0.0, 0.0, float(W), float(H)))
+    grid = A.make_grid((0.0, 0.0, float(W), float(H)), dims=(W, H))
+    run = A.ReductionRun(grid, 7, path=2)                     # sum + count + max planes
+    try:
+        run.scatter(x, y, v)
+        st = run.stats()
+        assert st.path == 1 and st.num_bins == -(-W // st.lds_tile_w) * -(-H // st.lds_tile_h), shape
+        got_s, got_c, got_m = run.plane("d_sum"), run.plane("d_wgt"), run.plane("d_max")
+    finally:
+        run.close()
+    want_c = np.nan_to_num(O.run(og, O.COUNT, x, y, v))
+    assert np.array_equal(got_c, want_c), shape
+    want_s = np.nan_to_num(O.run(og, O.SUM, x, y, v, wide=True).astype(np.float64))
+    assert (np.abs(got_s - want_s) <= 1e-5 * np.maximum(1.0, np.abs(want_s))).all(), shape
+    want_m = O.run(og, O.MAX, x, y, v)
+    occ = want_c > 0
+    assert np.array_equal(got_m[occ], want_m[occ]), shape
