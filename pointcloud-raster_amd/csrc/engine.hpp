@@ -123,7 +123,7 @@ int fill_identity(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl);
 // 8-byte Value or Index records.  two_level_shift: 0 when not applicable (disabled, or more than kMaxTiles tiles).
 int two_level_shift(const pcr_hip_engine* e, int tiles);
 int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* x, const double* y, const float* v,
-                         uint64_t n, bool index_records, unsigned item_records, BinBuffers* out);
+                         uint64_t n, bool index_records, unsigned item_records, BinBuffers* out, bool every_bin = false);
 
 // direct path (global atomics), scatter_direct.hip
 int direct_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,

@@ -55,6 +55,7 @@ constexpr int kCountThreads = 512;
 // Blocks [0, full_blocks) take b.chunk points each, the blocks after them 4096 points each (the ragged end): the SAME
 // block -> points mapping as k_bin_scatter's, because with nvx = 8 the counts are kept per virtual XCD (blockIdx % 8) and a
 // point must be counted under the virtual XCD that will store its record (see bin_points).  nvx = 1: one count per bin.
+template <bool MULTI>
 __global__ void __launch_bounds__(kCountThreads)
 k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, const double* __restrict__ x, const double* __restrict__ y,
             uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
@@ -68,14 +69,22 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
     const bool one_tile = g.tiles_x * g.tiles_y == 1;
-    // a scatter block's points are counted by `split` workgroups (all under the scatter block's virtual XCD): the count pass
-    // wants more, shorter workgroups than the scatter pass has chunks
-    const unsigned nsplit = full_blocks * (unsigned)split;
+    // Block -> points.  MULTI = false: a scatter block's points are counted by `split` workgroups (all under the scatter
+    // block's virtual XCD) -- the count pass wants more, shorter workgroups than the scatter pass has chunks.  MULTI = true
+    // (`split` then holds cb): ONE workgroup counts cb scatter blocks of one virtual XCD (blocks vx, vx + 8, ...) -- with
+    // ~100 bins, the first level of the two-level sort, every workgroup flushes onto the same few hundred counters, and
+    // 500 M points on a 16384 x 8192 window made 40 690 such workgroups: k_bin_count 2.44 -> 1.90-1.99 ms with eight blocks
+    // each (count_blocks()).  (A separate instantiation: as one kernel with a loop of one, the C2 count pass lost 9 %.)
+    // The ragged end's 4096-point blocks come last, one workgroup each.
+    const unsigned nsplit = MULTI ? (unsigned)nvx * (((full_blocks + nvx - 1) / nvx + split - 1) / split) : full_blocks * (unsigned)split;
     const bool tail = blockIdx.x >= nsplit;
-    const unsigned sblock = tail ? full_blocks + (blockIdx.x - nsplit) : blockIdx.x / (unsigned)split;      // the scatter pass's block
-    const int len = tail ? 4096 : b.chunk / split;
-    const uint64_t base = tail ? (uint64_t)full_blocks * b.chunk + (uint64_t)(blockIdx.x - nsplit) * 4096
-                               : (uint64_t)sblock * b.chunk + (uint64_t)(blockIdx.x % (unsigned)split) * len;
+    const unsigned sblock = tail ? full_blocks + (blockIdx.x - nsplit)                               // the scatter pass's block
+                          : MULTI ? (blockIdx.x / (unsigned)nvx) * (unsigned)split * (unsigned)nvx + (blockIdx.x & (unsigned)(nvx - 1))
+                                  : blockIdx.x / (unsigned)split;
+    const int len = tail ? 4096 : MULTI ? b.chunk : b.chunk / split;
+    uint64_t base = tail ? (uint64_t)full_blocks * b.chunk + (uint64_t)(blockIdx.x - nsplit) * 4096
+                         : MULTI ? (uint64_t)sblock * b.chunk
+                                 : (uint64_t)sblock * b.chunk + (uint64_t)(blockIdx.x % (unsigned)split) * len;
     unsigned my_valid = 0;
     // The routing is done once: pass B reads the 4-byte key written here instead of x, y (16 B).
     auto handle = [&](uint64_t i, double wx, double wy) -> unsigned {
@@ -88,6 +97,12 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
         }
         return 0xFFFFFFFFu;
     };
+    const int nranges = MULTI && !tail ? split : 1;
+    for (int t = 0; t < nranges; ++t) {
+    if (MULTI && t > 0) {
+        if (sblock + (unsigned)t * (unsigned)nvx >= full_blocks) break;
+        base += (uint64_t)nvx * b.chunk;
+    }
     const bool full = base + (uint64_t)len <= n &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     if (full) {
@@ -122,6 +137,7 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
             keys[i] = handle(i, x[i], y[i]);
         }
     }
+    }
     if (my_valid) atomicAdd(&any_valid, my_valid);
     __syncthreads();
     unsigned* mine = bin_count + (size_t)(sblock & (unsigned)(nvx - 1)) * b.nbins;
@@ -152,6 +168,16 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
 // the step 0.606 / 0.612 -> 0.591 / 0.592 (two: 0.194 / 0.180; seven: 0.208 / 0.213 -- every workgroup flushes its histogram
 // with up to nbins global atomics, so the split stops where that exceeds ~1/5 atomic per point).  With today's chunks
 // (scatter_shape: 12 288 points at C2's 1 376 bins) the rule leaves one workgroup per block: 4 069 of them, 5.3 rounds.
+// Scatter blocks per count workgroup (k_bin_count<true>): with few bins every workgroup's flush lands on the same few hundred
+// counters, and what matters is how MANY workgroups flush -- as many blocks per workgroup as still leave ~4 rounds of
+// workgroups (768 resident).  1: the split rule below applies instead.
+inline int count_blocks(int nbins, int blocks, int num_cus) {
+    if (nbins > 512) return 1;
+    int cb = 1;
+    while (cb < 16 && blocks / (cb * 2) >= 12 * num_cus) cb *= 2;
+    return cb;
+}
+
 inline int count_split(int chunk, int nbins) {
     int s = 4;
     while (s > 1 && (chunk % s != 0 || (chunk / s) % 1024 != 0 || chunk / s < 5 * nbins)) s >>= 1;
@@ -799,10 +825,18 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         bc.chunk = sh.chunk();
         const int full_blocks = scatter_full_blocks(sh, v, n, kind == RecordKind::Index);
         const uint64_t done = (uint64_t)full_blocks * sh.chunk();
-        const int split = count_split(bc.chunk, b.nbins);
-        const unsigned cblocks = (unsigned)full_blocks * (unsigned)split + (unsigned)((n - done + 4095) / 4096);
-        hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
-                           gd, bc, (unsigned)full_blocks, split, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+        const int cb = count_blocks(b.nbins, full_blocks, e->num_cus);
+        const unsigned tail_blocks = (unsigned)((n - done + 4095) / 4096);
+        if (cb > 1) {
+            const unsigned cblocks = (unsigned)nvx * (((unsigned)(full_blocks + nvx - 1) / nvx + cb - 1) / cb) + tail_blocks;
+            hipLaunchKernelGGL(k_bin_count<true>, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
+                               gd, bc, (unsigned)full_blocks, cb, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+        } else {
+            const int split = count_split(bc.chunk, b.nbins);
+            hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)full_blocks * (unsigned)split + tail_blocks), dim3(kCountThreads),
+                               (size_t)b.nbins * 4, e->stream,
+                               gd, bc, (unsigned)full_blocks, split, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+        }
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
@@ -835,7 +869,7 @@ int two_level_shift(const pcr_hip_engine* e, int tiles) {
 }
 
 int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* x, const double* y, const float* v,
-                         uint64_t n, bool index_records, unsigned item_records, BinBuffers* out) {
+                         uint64_t n, bool index_records, unsigned item_records, BinBuffers* out, bool every_bin) {
     BinGeom l1 = tiles;                                                   // first level: groups of tiles
     l1.nbins = (tiles.nbins + (1 << tiles.sup_shift) - 1) >> tiles.sup_shift;
     const ScatterShape sh1 = scatter_shape(l1.nbins);
@@ -849,9 +883,9 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
 
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
-    const size_t o_count1 = carve((size_t)nvx * l1.nbins * 4), o_cursor1 = carve((size_t)nvx * l1.nbins * 4), o_nitems1 = carve(4);
+    const size_t o_count1 = carve((size_t)nvx * l1.nbins * 4), o_cursor1 = carve((size_t)nvx * l1.nbins * 4), o_nitems1 = carve(8);
     const size_t o_items1 = carve((size_t)max_items1 * sizeof(BinItem));
-    const size_t o_count2 = carve((size_t)tiles.nbins * 4), o_cursor2 = carve((size_t)tiles.nbins * 4), o_nitems2 = carve(4);
+    const size_t o_count2 = carve((size_t)tiles.nbins * 4), o_cursor2 = carve((size_t)tiles.nbins * 4), o_nitems2 = carve(8);
     const size_t o_items2 = carve((size_t)max_items2 * sizeof(BinItem));
     const size_t o_keys = carve((size_t)n * 4), o_rec1 = carve((size_t)n * 8), o_rec2 = carve((size_t)n * 8);
     int rc = ensure_scratch(e, off);
@@ -867,10 +901,18 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     PCR_HIP_TRY(hipMemsetAsync(U(o_count2), 0, (size_t)tiles.nbins * 4, e->stream));
     {
         ScopedKernelTimer t(e, "k_bin_count");
-        const int split = count_split(l1.chunk, l1.nbins);
-        const unsigned cblocks = (unsigned)full_blocks * (unsigned)split + (blocks - (unsigned)full_blocks);
-        hipLaunchKernelGGL(k_bin_count, dim3(cblocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
-                           e->gd, l1, (unsigned)full_blocks, split, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+        const int cb = count_blocks(l1.nbins, full_blocks, e->num_cus);
+        const unsigned tail_blocks = blocks - (unsigned)full_blocks;
+        if (cb > 1) {
+            const unsigned cblocks = (unsigned)nvx * (((unsigned)(full_blocks + nvx - 1) / nvx + cb - 1) / cb) + tail_blocks;
+            hipLaunchKernelGGL(k_bin_count<true>, dim3(cblocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
+                               e->gd, l1, (unsigned)full_blocks, cb, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+        } else {
+            const int split = count_split(l1.chunk, l1.nbins);
+            hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)full_blocks * (unsigned)split + tail_blocks), dim3(kCountThreads),
+                               (size_t)l1.nbins * 4, e->stream,
+                               e->gd, l1, (unsigned)full_blocks, split, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+        }
     }
     {
         ScopedKernelTimer t(e, "k_bin_scan");
@@ -888,7 +930,7 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
     {
         ScopedKernelTimer t(e, "k_bin_scan");
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kThreads), 0, e->stream, tiles.nbins, 1, item_records, U(o_count2),
-                           U(o_cursor2), d_items2, U(o_nitems2), 0);
+                           U(o_cursor2), d_items2, U(o_nitems2), every_bin ? 1 : 0);
     }
     {
         ScopedKernelTimer t(e, "k_sub_scatter");
@@ -939,7 +981,7 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     // no pass of its own.  Needs whole float4 groups per plane row (the merge's vector form is per row, the scalar form
     // covers the rest); anything else (two sort levels, several bands) fills the planes first.
     const int64_t cells = (int64_t)e->gd.st_rows * e->gd.W;
-    const bool define_all = e->planes_fresh == 2 && nbands == 1 && shift == 0 && cells % 4 == 0 &&
+    const bool define_all = e->planes_fresh == 2 && (nbands == 1 || shift > 0) && cells % 4 == 0 &&
                             ((reinterpret_cast<uintptr_t>(pl.sum) | reinterpret_cast<uintptr_t>(pl.wgt) |
                               reinterpret_cast<uintptr_t>(pl.mx) | reinterpret_cast<uintptr_t>(pl.mn)) & 15) == 0;
     if (e->planes_fresh == 2 && !define_all) {
@@ -950,11 +992,16 @@ int binned_point(pcr_hip_engine* e, uint32_t mask, const PlanesDev& pl,
     if (shift > 0) {                                            // one sweep, two sort levels
         b.sup_shift = shift;
         BinBuffers bb{};
-        int rc = bin_points_two_level(e, b, x, y, v, n, false, kPointItemRecords, &bb);
+        int rc = bin_points_two_level(e, b, x, y, v, n, false, kPointItemRecords, &bb, define_all);
         if (rc) return rc;
+        if (define_all)
+            hipLaunchKernelGGL(k_fill_if, dim3(2048), dim3(256), 0, e->stream, bb.n_items, pl, mask, cells / 4);
+        const bool fused = define_all && e->fused_outs.n > 0 && e->fused_done && e->gd.W % 4 == 0 &&
+                           e->gd.own_r0 == e->gd.st_r0 && e->gd.own_r1 - e->gd.own_r0 == e->gd.st_rows;
+        e->fused_taken = fused;
         ScopedKernelTimer t(e, "k_tile_accum");
         switch (mask) {
-#define PCR_ACC(M) case M: launch_accum<M>(e, e->gd, b, pl, bb); break;
+#define PCR_ACC(M) case M: launch_accum<M>(e, e->gd, b, pl, bb, fused); break;
             PCR_ACC(1) PCR_ACC(2) PCR_ACC(3) PCR_ACC(4) PCR_ACC(5) PCR_ACC(6) PCR_ACC(7) PCR_ACC(8)
             PCR_ACC(9) PCR_ACC(10) PCR_ACC(11) PCR_ACC(12) PCR_ACC(13) PCR_ACC(14) PCR_ACC(15)
 #undef PCR_ACC

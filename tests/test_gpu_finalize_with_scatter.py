@@ -287,3 +287,25 @@ def test_merge_touched_keeps_the_stored_bands_unless_a_flag_changes():
             m = ~np.isnan(want_s)
             assert np.allclose(sm[m], want_s[m], rtol=1e-5, atol=1e-5)
         assert np.array_equal(np.nan_to_num(ct), np.nan_to_num(O.run(og, O.COUNT, x, y, v)))
+
+
+def test_two_level_sweep_defines_the_planes_and_stores_the_bands(monkeypatch):
+    """A window with more LDS tiles than one binning pass takes (PCR_HIP_DEBUG_MAX_BINS lowers the limit) is sorted in two
+    levels; its tile pass, too, defines every cell of undefined planes and stores the bands -- poisoned memory, a sparse
+    cloud (empty tiles get their identity from empty work items), sixteen reference tiles."""
+    monkeypatch.setenv("PCR_HIP_DEBUG_MAX_BINS", "12")          # read by pcr_hip_engine_create
+    monkeypatch.setenv("PCR_HIP_DEBUG_TWO_LEVEL", "1")
+    G, n = 1024, 60_000
+    x, y, v = sparse_cloud(G, n, 17)
+    og = O.make_grid((0, 0, G, G), tile=(256, 256))
+    poison_device_memory(8 * G * G * 4)
+    p = pcr.Pipeline.create(config_for(og, [spec(t) for t in ALL6], scatter_path=2))
+    p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    info = p.last_scatter()
+    assert info["path"] == "binned" and info["num_bins"] > 12 and info["bands_with_scatter"] == 1
+    p.finalize()
+    check_point_bands(p, og, x, y, v, ALL6)
+    # and a second ingest on top of what the two-level sweep defined
+    p.ingest(cloud_from(x + 300.0, y - 200.0, {"value": v}, "device"))
+    p.finalize()
+    check_point_bands(p, og, np.concatenate([x, x + 300.0]), np.concatenate([y, y - 200.0]), np.concatenate([v, v]), ALL6)
