@@ -287,3 +287,26 @@ def test_point_scatter_shapes_by_bin_count(A, dims, shape):
     want_m = O.run(og, O.MAX, x, y, v)
     occ = want_c > 0
     assert np.array_equal(got_m[occ], want_m[occ]), shape
+
+
+def test_count_pass_with_several_scatter_blocks_per_workgroup(A):
+    """Few bins and many points: the count pass gives a workgroup several scatter blocks of one virtual XCD (k_bin_count<true>:
+    80 M points on a 1024^2 grid, 88 LDS tiles, 6 511 scatter blocks -> two per workgroup), ragged end included -- Count
+    bit-exact and conserved, Sum against the oracle."""
+    G, n = 1024, 80_000_123
+    rng = np.random.default_rng(99)
+    x, y = rng.uniform(0, G, n), rng.uniform(0, G, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    og = O.make_grid((0.0, 0.0, float(G), float(G)))
+    grid = A.make_grid((0.0, 0.0, float(G), float(G)), dims=(G, G))
+    run = A.ReductionRun(grid, 3, path=2)
+    try:
+        run.scatter(x, y, v)
+        assert run.stats().path == 1 and run.stats().points_valid == n
+        got_s, got_c = run.plane("d_sum"), run.plane("d_wgt")
+    finally:
+        run.close()
+    want_c = np.nan_to_num(O.run(og, O.COUNT, x, y, v))
+    assert np.array_equal(got_c, want_c) and got_c.astype(np.float64).sum() == n
+    want_s = np.nan_to_num(O.run(og, O.SUM, x, y, v, wide=True).astype(np.float64))
+    assert (np.abs(got_s - want_s) <= 1e-5 * np.maximum(1.0, np.abs(want_s))).all()
