@@ -438,7 +438,7 @@ struct ScatterShape {
     int chunk() const { return threads * per; }
 };
 inline ScatterShape scatter_shape(int nbins) {
-    if (nbins <= 2048) return {512, 24, 8192};
+    if (nbins <= 2040) return {512, 24, 8192};               // (64 KB + 8 B per bin + the static words, twice, within 160 KB)
     if (nbins <= 4032) return {1024, 16, 16384};            // 128 KB + 8 B per bin (+ the static words) = the whole LDS
     return {1024, 24, 8192};                                // (a quarter of C5, 5 504 bins: step 2.80 -> 2.72-2.76 ms against 1024 x 16; x 28: 2.86-2.95)
 }
