@@ -153,6 +153,14 @@ k_halo_merge(uint32_t kind, float* __restrict__ dst, const float* __restrict__ s
     }
 }
 
+// dst[i] = identity of the plane's kind: what an apron row holds once its contents have gone to the row's owner
+__global__ void __launch_bounds__(256)
+k_halo_reset(uint32_t kind, float* __restrict__ dst, int64_t n) {
+    const float id = kind == PCR_HIP_PLANE_MAX ? -FLT_MAX : kind == PCR_HIP_PLANE_MIN ? FLT_MAX : 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = id;
+}
+
 }  // namespace
 
 struct pcr_hip_comm {
@@ -383,6 +391,15 @@ int pcr_hip_comm_halo_reduce(pcr_hip_comm* c, const pcr_hip_halo_plane* planes, 
     for (int p = 0; p < nplanes; ++p) {
         float* plane = planes[p].d_plane;
         const float* land = c->d_recv + (size_t)p * (up_slot + dn_slot);
+        // The apron rows that were sent now live in their owner's rows: back to the plane's identity (stream order puts
+        // this after the sends), so that a LATER exchange -- the reference keeps state across finalize and its benchmarks
+        // re-finalize one pipeline, src/engine/pipeline.cpp:1344-1364 -- carries only what was accumulated since.
+        if (send_up > 0)
+            hipLaunchKernelGGL(k_halo_reset, dim3(grid_of((size_t)send_up * width)), dim3(256), 0, st, planes[p].kind,
+                               plane, (int64_t)send_up * width);
+        if (send_dn > 0)
+            hipLaunchKernelGGL(k_halo_reset, dim3(grid_of((size_t)send_dn * width)), dim3(256), 0, st, planes[p].kind,
+                               plane + (size_t)(state_rows - send_dn) * width, (int64_t)send_dn * width);
         if (recv_up > 0)
             hipLaunchKernelGGL(k_halo_merge, dim3(grid_of(up_slot)), dim3(256), 0, st, planes[p].kind,
                                plane + (size_t)up_n * width, land, (int64_t)up_slot);

@@ -97,7 +97,10 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
         }
         return 0xFFFFFFFFu;
     };
-    const int nranges = MULTI && !tail ? split : 1;
+    // (MULTI: the last group of workgroups may start beyond the last full block -- full_blocks need not be a multiple of
+    // nvx -- and such a workgroup has nothing to count: its `base` would be the start of the ragged end, which the
+    // 4096-point blocks count.  It still reaches the barriers and the (empty) flush below.)
+    const int nranges = MULTI && !tail ? (sblock >= full_blocks ? 0 : split) : 1;
     for (int t = 0; t < nranges; ++t) {
     if (MULTI && t > 0) {
         if (sblock + (unsigned)t * (unsigned)nvx >= full_blocks) break;

@@ -28,6 +28,10 @@ def row_block(rank, world, height, align=1):
     return min(u0 * align, height), min(u1 * align, height)
 
 
+_FLT_MAX = 3.4028234663852886e38
+_IDENTITY = {PLANE_SUM: 0.0, PLANE_WGT: 0.0, PLANE_MAX: -_FLT_MAX, PLANE_MIN: _FLT_MAX}
+
+
 def _merge(dst, src, kind):
     if kind in (PLANE_SUM, PLANE_WGT):
         dst.add_(src)
@@ -47,8 +51,10 @@ def exchange_halos(planes, own, state_row0, halo, rank, world, blocks=None, grou
     halo:       apron rows kept beyond each side of the owned block (same on every rank)
     blocks:     list of (r0, r1) of every rank (defaults to neighbours holding exactly `halo` rows)
 
-    After the call rows [r0, r1) of every plane contain the contributions of ALL ranks.
-    Apron rows are left as they are (finalize never reads them).
+    After the call rows [r0, r1) of every plane contain the contributions of ALL ranks, and the apron rows that
+    were sent hold the plane's identity again (0 / -FLT_MAX / FLT_MAX): their contents now live in their owner's rows,
+    so a later exchange -- state survives finalize(), src/engine/pipeline.cpp:1344-1364 -- carries only what was
+    accumulated since and nothing is counted twice.
     A footprint never reaches further than `halo` rows, so only rank-1 and rank+1 hold data
     for this rank as long as every block is at least `halo` rows tall (checked).
     """
@@ -61,7 +67,7 @@ def exchange_halos(planes, own, state_row0, halo, rank, world, blocks=None, grou
                 raise ValueError("row block shorter than the glyph halo: use fewer ranks or a smaller radius")
     rows_in_state = planes[0][0].shape[0]
     s1 = state_row0 + rows_in_state
-    ops, recvs = [], []
+    ops, recvs, sent = [], [], []
     # gloo cannot move device tensors point-to-point: stage through host memory (rehearsals and
     # tests only; the production backend is nccl = RCCL, which sends from HBM over xGMI)
     stage = dist.get_backend(group) == "gloo" and planes[0][0].is_cuda
@@ -79,6 +85,7 @@ def exchange_halos(planes, own, state_row0, halo, rank, world, blocks=None, grou
         if rank > 0:
             if up_n > 0:
                 ops.append(dist.P2POp(dist.isend, outgoing(t[:up_n]), rank - 1, group))
+                sent.append((t[:up_n], kind))
             # rank-1 holds min(halo, rows I own) of my top rows
             n = min(halo, r1 - r0)
             buf = incoming(n, t)
@@ -87,6 +94,7 @@ def exchange_halos(planes, own, state_row0, halo, rank, world, blocks=None, grou
         if rank < world - 1:
             if dn_n > 0:
                 ops.append(dist.P2POp(dist.isend, outgoing(t[rows_in_state - dn_n:]), rank + 1, group))
+                sent.append((t[rows_in_state - dn_n:], kind))
             n = min(halo, r1 - r0)
             buf = incoming(n, t)
             ops.append(dist.P2POp(dist.irecv, buf, rank + 1, group))
@@ -95,6 +103,8 @@ def exchange_halos(planes, own, state_row0, halo, rank, world, blocks=None, grou
         req.wait()
     for dst, buf, kind in recvs:
         _merge(dst, buf.to(dst.device) if stage else buf, kind)
+    for rows, kind in sent:                       # (after the waits: the sends have left the rows)
+        rows.fill_(_IDENTITY[kind])
 
 
 def allreduce_touched(touched, group=None):

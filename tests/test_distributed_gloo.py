@@ -59,10 +59,30 @@ def _worker(rank, world, port, out_dir):
         planes = [(torch.from_numpy(num), PLANE_SUM), (torch.from_numpy(den), PLANE_WGT),
                   (torch.from_numpy(mx), PLANE_MAX)]
         exchange_halos(planes, (r0, r1), s0, halo, rank, world, blocks=blocks)
+        # the apron rows that went to their owners hold the identity again
+        if rank > 0:
+            assert (num[: r0 - s0] == 0).all() and (den[: r0 - s0] == 0).all() and (mx[: r0 - s0] < -3e38).all()
+        if rank < world - 1:
+            assert (num[r1 - s0:] == 0).all() and (den[r1 - s0:] == 0).all()
+        first = dict(num=num[(r0 - s0):(r1 - s0)].copy(), den=den[(r0 - s0):(r1 - s0)].copy())
+        # ingest -> finalize -> ingest -> finalize (state survives finalize, src/engine/pipeline.cpp:1344-1364): a second
+        # cloud lands on the same planes (the tensors view these arrays) and a second exchange must carry only that
+        x2, y2 = rng.uniform(0, W, n), rng.uniform(0, H, n)
+        v2 = rng.uniform(0, 1, n).astype(np.float32)
+        rows2 = np.floor((y2 - og.max_y) / og.cell_size_y).clip(0, H - 1).astype(int)
+        m2 = (rows2 >= r0) & (rows2 < r1)
+        if m2.any():
+            num += np.nan_to_num(O.run(og, O.SUM, x2[m2], y2[m2], v2[m2], glyph=gl))[s0:s1]
+            den += np.nan_to_num(O.run(og, O.COUNT, x2[m2], y2[m2], v2[m2], glyph=gl))[s0:s1]
+        exchange_halos(planes, (r0, r1), s0, halo, rank, world, blocks=blocks)
+        np.savez(os.path.join(out_dir, f"second{rank}.npz"), num=num[(r0 - s0):(r1 - s0)], den=den[(r0 - s0):(r1 - s0)])
+        num2, den2 = num, den
+        num, den = first["num"], first["den"]
+        mx_own = mx[(r0 - s0):(r1 - s0)]
         touched = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
         allreduce_touched(touched)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), num=num[(r0 - s0):(r1 - s0)], den=den[(r0 - s0):(r1 - s0)],
-                 mx=mx[(r0 - s0):(r1 - s0)], own=np.array([r0, r1]), touched=touched.numpy())
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), num=num, den=den,
+                 mx=mx_own, own=np.array([r0, r1]), touched=touched.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -81,6 +101,10 @@ def test_halo_exchange_matches_unsharded(world, tmp_path):
     gl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=2.0, sigma_y=2.0, max_radius=float(halo))
     num = np.nan_to_num(O.run(og, O.SUM, x, y, v, glyph=gl))
     den = np.nan_to_num(O.run(og, O.COUNT, x, y, v, glyph=gl))
+    x2, y2 = rng.uniform(0, W, n), rng.uniform(0, H, n)
+    v2 = rng.uniform(0, 1, n).astype(np.float32)
+    num2 = num + np.nan_to_num(O.run(og, O.SUM, x2, y2, v2, glyph=gl))
+    den2 = den + np.nan_to_num(O.run(og, O.COUNT, x2, y2, v2, glyph=gl))
     rows_seen = 0
     for r in range(world):
         d = np.load(tmp_path / f"r{r}.npz")
@@ -88,6 +112,10 @@ def test_halo_exchange_matches_unsharded(world, tmp_path):
         rows_seen += r1 - r0
         np.testing.assert_allclose(d["num"], num[r0:r1], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(d["den"], den[r0:r1], rtol=1e-5, atol=1e-6)
+        # after the SECOND exchange: both clouds, every contribution exactly once (round 4 counted the first halo twice)
+        d2 = np.load(tmp_path / f"second{r}.npz")
+        np.testing.assert_allclose(d2["num"], num2[r0:r1], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(d2["den"], den2[r0:r1], rtol=1e-5, atol=1e-5)
         # max plane: my last `halo` rows received the lower neighbour's apron (100 + its rank)
         if r < world - 1:
             assert (d["mx"][-halo:] == 100 + r + 1).all() and (d["mx"][:-halo] == r).all()

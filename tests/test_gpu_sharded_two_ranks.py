@@ -165,3 +165,95 @@ def test_two_rank_point_pipelines_exchange_flags_only(tmp_path):
         assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"band {b}"
     # rows 60..63 of rank 1 lie in tile row 0, which only rank 0 touched: Sum there is 0.0, not NaN
     assert not np.isnan(parts[1]["b0"][:4]).any() and (parts[1]["b0"][:4] == 0.0).all()
+
+
+def _twice_inputs(k):
+    rng = np.random.default_rng(77 + k)
+    n = 20000
+    x, y = rng.uniform(0, G_W, n), rng.uniform(0, G_H, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    d = rng.uniform(0, np.pi, n).astype(np.float32)
+    return x, y, v, d
+
+
+def _twice_cfg(pcr):
+    cfg = pcr.PipelineConfig()
+    cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G_W), float(G_H))
+    cfg.grid.tile_width, cfg.grid.tile_height = 64, 64          # rows [0, 60) / [60, 120) cut tile row 0: every finalize exchanges
+    cfg.grid.compute_dimensions()
+    cfg.exec_mode = pcr.ExecutionMode.GPU
+    line = pcr.line_splat_spec("value", direction_channel="dir", default_half_length=5.0, max_radius_cells=7.0)
+    lcount = pcr.line_splat_spec("value", direction_channel="dir", default_half_length=5.0, max_radius_cells=7.0)
+    lcount.type = pcr.ReductionType.Count
+    gsum = pcr.gaussian_splat_spec("value", default_sigma=1.5, max_radius_cells=5.0)
+    gsum.type = pcr.ReductionType.Sum
+    cfg.reductions = [pcr.gaussian_splat_spec("value", default_sigma=1.5, max_radius_cells=5.0), gsum, line, lcount]
+    return cfg
+
+
+def _worker_twice(rank, world, port, out_dir, comm):
+    import torch                                   # before pcr: one shared HIP runtime
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+    import pcr
+    from pcr.distributed import ShardedPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = ShardedPipeline(_twice_cfg(pcr), rank, world, device_id=0, comm=comm)
+        out = {"own": np.array(sp.own), "halo": sp.halo}
+        for k in range(3):                          # ingest -> finalize, three times on ONE pipeline
+            x, y, v, d = _twice_inputs(k)
+            cloud = pcr.PointCloud.create(len(x))
+            cloud.set_x_array(x)
+            cloud.set_y_array(y)
+            cloud.add_channel("value", pcr.DataType.Float32)
+            cloud.set_channel_array_f32("value", v)
+            cloud.add_channel("dir", pcr.DataType.Float32)
+            cloud.set_channel_array_f32("dir", d)
+            sp.ingest(cloud.to_device())
+            sp.finalize()
+            if k == 1:
+                sp.finalize()                       # a finalize with nothing new in between changes nothing either
+            res = sp.result()
+            for b in range(4):
+                out[f"k{k}b{b}"] = np.array(res.band_array(b))
+        np.savez(os.path.join(out_dir, f"t{rank}.npz"), **out)
+        sp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pipeline_refinalizes_without_counting_the_halo_twice(tmp_path):
+    """ingest -> finalize -> ingest -> finalize (-> finalize) -> ingest -> finalize on two row-block shards with a Gaussian and a
+    Line group: state survives finalize (src/engine/pipeline.cpp:1344-1364; scripts/benchmarks/benchmark_glyph_full.py:232-246
+    re-finalizes one pipeline), so every exchange may carry only what was accumulated since the previous one -- round 4's
+    exchange left the apron rows as they were and the owner's boundary rows grew with every finalize."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcr_oracle_py as O
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_twice, args=(2, port, str(tmp_path), "torch"), nprocs=2, join=True)
+    og = O.make_grid((0, 0, G_W, G_H), tile=(64, 64))
+    gg = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=1.5, sigma_y=1.5, max_radius=5.0)
+    parts = [np.load(tmp_path / f"t{r}.npz") for r in range(2)]
+    assert int(parts[0]["halo"]) >= 6
+    xs, ys, vs, ds = [], [], [], []
+    for k in range(3):
+        x, y, v, d = _twice_inputs(k)
+        xs.append(x); ys.append(y); vs.append(v); ds.append(d)
+        X, Y, V, D = np.concatenate(xs), np.concatenate(ys), np.concatenate(vs), np.concatenate(ds)
+        lg = O.make_glyph(O.GLYPH_LINE, half_length=5.0, max_radius=7.0)
+        want = [O.run(og, O.WEIGHTED_AVERAGE, X, Y, V, glyph=gg), O.run(og, O.SUM, X, Y, V, glyph=gg),
+                O.run(og, O.WEIGHTED_AVERAGE, X, Y, V, glyph=lg, direction=D), O.run(og, O.COUNT, X, Y, V, glyph=lg, direction=D)]
+        for b, (rt, at) in enumerate([(1e-4, 1e-6), (1e-4, 1e-5), (1e-4, 1e-6), (0, 0)]):
+            got = np.vstack([parts[0][f"k{k}b{b}"], parts[1][f"k{k}b{b}"]])
+            w = want[b]
+            assert np.array_equal(np.isnan(got), np.isnan(w)), f"finalize {k}, band {b}: NaN mask"
+            m = ~np.isnan(w)
+            assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"finalize {k}, band {b}"

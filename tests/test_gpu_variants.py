@@ -289,11 +289,18 @@ def test_point_scatter_shapes_by_bin_count(A, dims, shape):
     assert np.array_equal(got_m[occ], want_m[occ]), shape
 
 
-def test_count_pass_with_several_scatter_blocks_per_workgroup(A):
+@pytest.mark.parametrize("n,two_level", [(80_000_123, False), (6145 * 12288 + 5000, False), (6145 * 12288 + 5000, True)],
+                         ids=["6510_blocks", "6145_blocks_last_group_past_the_end", "6145_blocks_two_level"])
+def test_count_pass_with_several_scatter_blocks_per_workgroup(A, n, two_level, monkeypatch):
     """Few bins and many points: the count pass gives a workgroup several scatter blocks of one virtual XCD (k_bin_count<true>:
     80 M points on a 1024^2 grid, 88 LDS tiles, 6 511 scatter blocks -> two per workgroup), ragged end included -- Count
-    bit-exact and conserved, Sum against the oracle."""
-    G, n = 1024, 80_000_123
+    bit-exact and conserved, Sum against the oracle.  6 145 full blocks (6145 % 8 = 1, (769 - 1) % 2 = 0): the last group of
+    count workgroups starts at blocks 6144 .. 6151, seven of which do not exist -- round 4's kernel let those seven count the
+    ragged end a second time; also as the first level of the two-level sort."""
+    if two_level:
+        monkeypatch.setenv("PCR_HIP_DEBUG_MAX_BINS", "24")          # read by pcr_hip_engine_create: 88 tiles -> two sort levels
+        monkeypatch.setenv("PCR_HIP_DEBUG_TWO_LEVEL", "1")
+    G = 1024
     rng = np.random.default_rng(99)
     x, y = rng.uniform(0, G, n), rng.uniform(0, G, n)
     v = rng.uniform(0, 1, n).astype(np.float32)
