@@ -271,6 +271,37 @@ def cpu_baseline(workload, G, sample_pts, seed, budget_s=14.0):
     if cal:
         res["port_over_reference"] = {k: c["port_over_reference"] for k, c in cal.items()}
         res["calibration"] = "oracle/calibration.json: port vs the true reference, both timed in the build container"
+    # beside the port: the PRODUCT's own ExecutionMode.CPU (the host engine of host/src/host_engine.cpp -- what a drop-in user
+    # of `exec_mode = CPU` gets), same sample, same reductions in ONE pipeline, at 1 thread and on all cores
+    try:
+        prod = {}
+        for label, threads in (("1", 1), ("all", ncores)):
+            cfg = pcr.PipelineConfig()
+            cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(G))
+            cfg.grid.cell_size_x, cfg.grid.cell_size_y = 1.0, -1.0
+            cfg.grid.compute_dimensions()
+            cfg.exec_mode = pcr.ExecutionMode.CPU
+            cfg.cpu_threads = threads
+            cfg.reductions = make_specs(workload)
+            pipe = pcr.Pipeline.create(cfg)
+            if pipe is None or pipe.engine() != "host":
+                raise RuntimeError("ExecutionMode.CPU did not give the host engine: " + pcr.pipeline_create_error())
+            cloud = make_cloud(x, y, v, ch)
+            best = None
+            for _ in range(2):                                   # (the first pass also pays the OpenMP team's start-up)
+                pipe = pcr.Pipeline.create(cfg)
+                t0 = time.perf_counter()
+                pipe.ingest(cloud)
+                pipe.finalize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            prod[label] = {"value": round(sample_pts / best / 1e6, 3), "cores": threads, "seconds": round(best, 3)}
+        res["product_host_engine"] = dict(prod, unit="Mpts/s", sample_points=sample_pts,
+                                          what="pcr.Pipeline with exec_mode = CPU (stripe-owned direct scatter, no sort, no "
+                                               "atomics), ingest + finalize of the same sample; checked against the oracle by "
+                                               "tests/test_host_engine.py")
+    except Exception as exc:                                     # informational: never cost the line
+        res["product_host_engine"] = {"error": repr(exc)}
     return res
 
 
@@ -405,6 +436,9 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="points per GPU (default 50 M; C5: 1e9 / N)")
     ap.add_argument("--grid", type=int, default=0, help="grid width (default 4096; C5: 16384)")
     ap.add_argument("--rows", type=int, default=0, help="--weak only: rows per GPU when not square")
+    ap.add_argument("--height", type=int, default=0,
+                    help="N > 1 (strong): grid rows when not square -- e.g. 5 ranks on 16384 x 10240 have the 2048-row blocks of the "
+                         "8-rank default (a one-GPU box admits six processes on its card, not eight)")
     ap.add_argument("--weak", action="store_true", help="N > 1: round 1's weak-scaled shape (tile-aligned blocks, no collective)")
     ap.add_argument("--path", default="auto", choices=["auto", "direct", "binned", "moments"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="points of the CPU baseline sample (0 = skip)")
@@ -428,6 +462,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # the driver's form: plain `python bench.py --gpus N`.  Decided before torch / pcr are imported.
         sys.exit(self_launch(args.gpus))
+    # a GPU pipeline that cannot get its device is an error here, never a host-engine fallback (the only host-engine run of
+    # this file asks for ExecutionMode.CPU by name: cpu_baseline's product leg)
+    os.environ.setdefault("PCR_REQUIRE_GPU_ENGINE", "1")
     _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -452,7 +489,7 @@ def main():
     workload = args.workload or ("C5_point" if strong else "C2")
     if strong:
         G = args.grid or 16384
-        H = G
+        H = args.height or G
         n = args.points or 1_000_000_000 // world
     else:
         G = args.grid or 4096
@@ -629,10 +666,43 @@ def main():
         res["touched_tiles"] = mine
         ok = ok and t_all == mine * world
         _, err = local(lambda: spg.pipe.finalize())
-        box.clear()
-        del spg
         if stage_failed("gauss finalize", err):
             return res
+
+        # ---- stage 4: the pipeline is finalized AGAIN (state survives finalize, src/engine/pipeline.cpp:1344-1364): a second
+        # exchange with nothing new accumulated must change nothing -- the apron rows that were sent hold the identity again --
+        # and after a second ingest of the same cloud the owned rows hold exactly twice the weight (round 4's exchange left
+        # the apron rows as they were and counted the first halo again at every finalize)
+        def s4():
+            spg.finalize()
+            spg.pipe.synchronize()
+            torch.cuda.synchronize()
+            planes = spg._plane_tensors()
+            s0 = spg.pipe.state_row_begin()
+            o0, o1 = spg.own
+            again = [float(t[o0 - s0:o1 - s0].double().sum().item()) for t, _ in planes]
+            halo_now = [float((t.double().sum() - t[o0 - s0:o1 - s0].double().sum()).abs().item()) for t, _ in planes]
+            spg.ingest(cloud)
+            spg.finalize()
+            spg.pipe.synchronize()
+            torch.cuda.synchronize()
+            twice = [float(t[o0 - s0:o1 - s0].double().sum().item()) for t, _ in planes]
+            return again, halo_now, twice
+
+        got, err = local(s4)
+        box.clear()
+        del spg
+        if stage_failed("gauss second finalize", err):
+            return res
+        again, halo_now, twice = got
+        unchanged = allsum([0 if a == b else 1 for a, b in zip(again, post)], torch.int64)
+        tot2 = allsum(halo_now + twice, torch.float64)
+        halo_left, twice_t = tot2[:k], tot2[k:]
+        rel2 = [abs(t2 - 2 * a) / max(abs(2 * a), 1e-30) for t2, a in zip(twice_t, pre_t)]
+        res["refinalize_owned_rows_unchanged"] = not any(unchanged)
+        res["refinalize_halo_rows_sum"] = [round(v, 6) for v in halo_left]
+        res["second_ingest_max_rel_diff_vs_twice"] = max(rel2) if rel2 else 0.0
+        ok = ok and not any(unchanged) and all(v == 0 for v in halo_left) and all(r <= 4e-6 for r in rel2)
         res["ok"] = bool(ok)
         return res
 
@@ -887,7 +957,7 @@ def main():
                     out["native_exchange"] = {"ok": False, "error": f"no answer within {args.native_check_limit:.0f} s (a hung "
                                               "collective); the timed legs above are unaffected"}
                     print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)                              # the line is out; a hung collective is still a failed run
 
         timer = threading.Timer(args.native_check_limit, bail)
         timer.daemon = True
@@ -899,7 +969,7 @@ def main():
         timer.cancel()
         with lock:
             if state["printed"]:
-                os._exit(0)
+                os._exit(3)
             state["printed"] = True                 # from here on the main thread prints
         hard_exit = not ne.get("ok", False)          # peers may be gone or stuck: do not wait for them in destroy_process_group
         if rank == 0:
@@ -919,8 +989,10 @@ def main():
 
     if world > 1:
         if hard_exit:
+            # the two transports disagreed (or the check raised): the line above says so, and so does the exit code -- the
+            # launcher (torchrun, self_launch) relays it
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)
         dist.destroy_process_group()
 
 

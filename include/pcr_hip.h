@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define PCR_HIP_ABI_VERSION 4   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2;
-                                 * 4: + engine_finalize_with_scatter / engine_finalize_taken / finalize_group_unless / touched_union */
+#define PCR_HIP_ABI_VERSION 5   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2;
+                                 * 4: + engine_finalize_with_scatter / engine_finalize_taken / finalize_group_unless / touched_union;
+                                 * 5 (round 5): + comm_alltoall_counts / comm_alltoallv / comm_gatherv / comm_xfer_plan; halo_reduce resets the sent apron rows */
 
 typedef enum pcr_hip_status {
     PCR_HIP_OK = 0,
@@ -340,6 +341,37 @@ int pcr_hip_comm_agree_max_i32(pcr_hip_comm* c, int32_t* h_inout, pcr_hip_stream
 int pcr_hip_comm_allreduce_max_u32(pcr_hip_comm* c, uint32_t* d_words, int count, pcr_hip_stream s);
 int pcr_hip_comm_allreduce_sum_f64(pcr_hip_comm* c, double* d_values, int count, pcr_hip_stream s);
 int pcr_hip_comm_stats(const pcr_hip_comm* c, uint64_t* halo_reduces, uint64_t* bytes_sent);
+/* Variable-size transfers (round 5), with the halo reduce's discipline: what every rank brings is all-gathered first (one
+ * pcr_hip_xfer_geom each, posted whatever the rank's own arguments were), every rank passes the same verdict on the gathered
+ * records (pcr_hip_comm_xfer_plan, pure host code), and either all post their sends and receives -- a receive sized from what
+ * its sender announced -- or all return PCR_HIP_INVALID_ARGUMENT with the same message.  Up to 8 arrays travel in ONE group with
+ * the same element counts (a cloud's x, y and channels; a result's bands); array a has elem_bytes[a]-byte elements (1..16).
+ *   alltoallv       SURVEY section 8e "device-side partition + peer copy": d_send[a] holds this rank's elements grouped by
+ *                   destination rank (h_send_counts[p] elements for rank p, in rank order: pcr_hip_route_scatter's output);
+ *                   d_recv[a] receives the groups of all ranks in rank order; h_recv_counts[p] (optional) = elements from p.
+ *                   recv_capacity = elements d_recv[a] can hold: a rank that would overflow makes every rank refuse.
+ *   alltoall_counts the counts alone (every rank's h_send_counts row to every rank): sizes the receive buffers beforehand.
+ *   gatherv         every rank's send_count elements per array to `root`, landing there in rank order (the row strips of a
+ *                   sharded result -> one grid, src/engine/pipeline.cpp:1175-1186, 1351-1361 write ONE file).
+ * A rank's own group is a device-to-device copy; a world of one needs no RCCL at all.  All on the caller's stream. */
+#define PCR_HIP_MAX_XFER_ARRAYS 8
+typedef struct pcr_hip_xfer_geom {
+    int32_t narrays;
+    int32_t elem_bytes[PCR_HIP_MAX_XFER_ARRAYS];
+    int32_t root;              /* gatherv: the receiving rank; alltoallv: -1 */
+    int32_t valid;             /* 0: this rank's own arguments were unusable -- everyone refuses */
+    int32_t reserved_;
+    uint64_t recv_capacity;    /* elements per array this rank can take */
+    uint64_t send_counts[PCR_HIP_MAX_ROUTE_PARTS];   /* elements per array this rank sends to rank p */
+} pcr_hip_xfer_geom;
+int pcr_hip_comm_alltoall_counts(pcr_hip_comm* c, const uint64_t* h_send_counts, uint64_t* h_recv_counts, pcr_hip_stream s);
+int pcr_hip_comm_alltoallv(pcr_hip_comm* c, int narrays, const void* const* d_send, void* const* d_recv, const int32_t* elem_bytes,
+                           const uint64_t* h_send_counts, uint64_t recv_capacity, uint64_t* h_recv_counts, pcr_hip_stream s);
+int pcr_hip_comm_gatherv(pcr_hip_comm* c, int narrays, const void* const* d_send, void* const* d_recv, const int32_t* elem_bytes,
+                         uint64_t send_count, uint64_t recv_capacity, uint64_t* h_recv_counts, int root, pcr_hip_stream s);
+/* send_offsets / recv_offsets: world + 1 entries (the last = totals); recv_counts: world entries. */
+int pcr_hip_comm_xfer_plan(const pcr_hip_xfer_geom* all, int world, int rank, uint64_t* send_offsets, uint64_t* recv_counts,
+                           uint64_t* recv_offsets);
 
 /* Per-kernel timing with HIP events on the engine's stream (for roofline reporting).
  * While enabled every kernel the engine launches is bracketed by two events; _read drains the

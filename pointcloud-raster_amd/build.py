@@ -71,7 +71,7 @@ def build_host(force=False):
     hdrs.append(os.path.join(ROOT, "include", "pcr_hip.h"))
     hdr_t = newest(hdrs)
     cxx = os.environ.get("CXX", "g++")
-    flags = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+    flags = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-fopenmp", "-ffp-contract=off",
              "-I" + os.path.join(HERE, "host", "include"), "-I" + os.path.join(ROOT, "include"),
              "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
     jobs, objs = [], []
@@ -87,7 +87,7 @@ def build_host(force=False):
     hip_so = os.path.join(LIB, "libpcr_hip.so")
     if jobs or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(hip_so):
         run([cxx, "-shared", "-o", out] + objs +
-            ["-L" + LIB, "-lpcr_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/../../lib", "-Wl,--no-undefined",
+            ["-L" + LIB, "-lpcr_hip", "-lz", "-pthread", "-fopenmp", "-Wl,-rpath,$ORIGIN/../../lib", "-Wl,--no-undefined",
              "-L" + sysconfig.get_config_var("LIBDIR"), "-lpython" + sysconfig.get_config_var("LDVERSION")])
     return out
 

@@ -168,8 +168,9 @@ struct pcr_hip_comm {
     int rank = 0, world = 1, device = 0;
     float* d_recv = nullptr;            // grow-only landing area for the neighbours' rows
     size_t recv_cap = 0;
-    int32_t* d_agree = nullptr;         // (world + 1) geometry records: [0] = mine, [1 ..] = everyone's (all-gather target)
+    int32_t* d_agree = nullptr;         // (world + 1) agreement records: [0] = mine, [1 ..] = everyone's (all-gather target)
     int32_t* h_agree = nullptr;         // page-locked mirror
+    size_t agree_ints = 0;              // int32 per record the two blocks are sized for
     uint64_t halo_reduces = 0, bytes_sent = 0, agreements = 0;
 };
 
@@ -180,19 +181,37 @@ static_assert(sizeof(pcr_hip_halo_geom) == 10 * sizeof(int32_t), "pcr_hip_halo_g
 
 // Every rank's record to every rank: H2D of mine, ncclAllGather, D2H of all, stream sync.  The ONLY thing a rank does
 // before it knows what the others brought -- so it is posted unconditionally, whatever this rank's own arguments were.
-int gather_geoms(pcr_hip_comm* c, Rccl* r, const pcr_hip_halo_geom& mine, pcr_hip_halo_geom* all, hipStream_t st) {
-    if (!c->d_agree) {
-        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom)));
-        PCR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom), hipHostMallocDefault));
+int ensure_agree(pcr_hip_comm* c, size_t ints, hipStream_t st) {
+    if (c->d_agree && c->agree_ints >= ints) return PCR_HIP_OK;
+    if (c->d_agree) {
+        PCR_HIP_TRY(hipStreamSynchronize(st));                    // (an earlier agreement's copies may still be in flight)
+        (void)hipFree(c->d_agree);
+        (void)hipHostFree(c->h_agree);
+        c->d_agree = c->h_agree = nullptr;
+        c->agree_ints = 0;
     }
-    __builtin_memcpy(c->h_agree, &mine, sizeof mine);
-    PCR_HIP_TRY(hipMemcpyAsync(c->d_agree, c->h_agree, sizeof mine, hipMemcpyHostToDevice, st));
-    PCR_RCCL_TRY(r, r->AllGather(c->d_agree, c->d_agree + kGeomInts, (size_t)kGeomInts, ncclInt32, c->comm, st), "ncclAllGather");
-    PCR_HIP_TRY(hipMemcpyAsync(c->h_agree + kGeomInts, c->d_agree + kGeomInts, (size_t)c->world * sizeof mine, hipMemcpyDeviceToHost, st));
+    PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_agree), (size_t)(c->world + 1) * ints * sizeof(int32_t)));
+    PCR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_agree), (size_t)(c->world + 1) * ints * sizeof(int32_t), hipHostMallocDefault));
+    c->agree_ints = ints;
+    return PCR_HIP_OK;
+}
+
+// One record of `ints` int32 from every rank to every rank.
+int gather_records(pcr_hip_comm* c, Rccl* r, const void* mine, void* all, size_t ints, hipStream_t st) {
+    int rc = ensure_agree(c, ints, st);
+    if (rc) return rc;
+    __builtin_memcpy(c->h_agree, mine, ints * 4);
+    PCR_HIP_TRY(hipMemcpyAsync(c->d_agree, c->h_agree, ints * 4, hipMemcpyHostToDevice, st));
+    PCR_RCCL_TRY(r, r->AllGather(c->d_agree, c->d_agree + ints, ints, ncclInt32, c->comm, st), "ncclAllGather");
+    PCR_HIP_TRY(hipMemcpyAsync(c->h_agree + ints, c->d_agree + ints, (size_t)c->world * ints * 4, hipMemcpyDeviceToHost, st));
     PCR_HIP_TRY(hipStreamSynchronize(st));
-    __builtin_memcpy(all, c->h_agree + kGeomInts, (size_t)c->world * sizeof mine);
+    __builtin_memcpy(all, c->h_agree + ints, (size_t)c->world * ints * 4);
     c->agreements++;
     return PCR_HIP_OK;
+}
+
+int gather_geoms(pcr_hip_comm* c, Rccl* r, const pcr_hip_halo_geom& mine, pcr_hip_halo_geom* all, hipStream_t st) {
+    return gather_records(c, r, &mine, all, (size_t)kGeomInts, st);
 }
 
 }  // namespace
@@ -423,10 +442,7 @@ int pcr_hip_comm_agree_max_i32(pcr_hip_comm* c, int32_t* h_inout, pcr_hip_stream
     PCR_HIP_TRY(hipGetDevice(&prev));
     if (prev != c->device) PCR_HIP_TRY(hipSetDevice(c->device));
     struct Restore { int prev, dev; ~Restore() { if (prev != dev) (void)hipSetDevice(prev); } } restore{prev, c->device};
-    if (!c->d_agree) {
-        PCR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom)));
-        PCR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_agree), (size_t)(c->world + 1) * sizeof(pcr_hip_halo_geom), hipHostMallocDefault));
-    }
+    { int rc = ensure_agree(c, (size_t)kGeomInts, st); if (rc) return rc; }
     c->h_agree[0] = *h_inout;
     PCR_HIP_TRY(hipMemcpyAsync(c->d_agree, c->h_agree, sizeof(int32_t), hipMemcpyHostToDevice, st));
     PCR_RCCL_TRY(r, r->AllReduce(c->d_agree, c->d_agree, 1, ncclInt32, ncclMax, c->comm, st), "ncclAllReduce");
@@ -461,6 +477,160 @@ int pcr_hip_comm_stats(const pcr_hip_comm* c, uint64_t* halo_reduces, uint64_t* 
     if (halo_reduces) *halo_reduces = c->halo_reduces;
     if (bytes_sent) *bytes_sent = c->bytes_sent;
     return PCR_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---- variable-size transfers between the ranks: all-to-all (an unrouted cloud's points to their owners) and gather
+//      (the ranks' finished row strips to one rank), with the same discipline as the halo reduce: what every rank brings is
+//      all-gathered first, every rank passes the same verdict on it, and a receive is sized from what its sender announced.
+
+namespace {
+constexpr int kXferInts = (int)(sizeof(pcr_hip_xfer_geom) / sizeof(int32_t));
+static_assert(sizeof(pcr_hip_xfer_geom) % sizeof(int32_t) == 0, "pcr_hip_xfer_geom is whole int32 words");
+
+int xfer(pcr_hip_comm* c, int narrays, const void* const* d_send, void* const* d_recv, const int32_t* elem_bytes,
+         const uint64_t* h_send_counts, uint64_t recv_capacity, uint64_t* h_recv_counts, int root, pcr_hip_stream s, const char* what) {
+    PCR_REQUIRE(c, std::string(what) + ": null communicator");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    pcr_hip_xfer_geom mine{};
+    mine.narrays = narrays;
+    mine.root = root;
+    mine.recv_capacity = recv_capacity;
+    bool ok_local = narrays >= 1 && narrays <= PCR_HIP_MAX_XFER_ARRAYS && d_send && d_recv && elem_bytes && h_send_counts &&
+                    c->world <= PCR_HIP_MAX_ROUTE_PARTS && root >= -1 && root < c->world;
+    uint64_t send_total = 0;
+    for (int p = 0; ok_local && p < c->world; ++p) { mine.send_counts[p] = h_send_counts[p]; send_total += h_send_counts[p]; }
+    for (int a = 0; ok_local && a < narrays; ++a) {
+        mine.elem_bytes[a] = elem_bytes[a];
+        ok_local = elem_bytes[a] > 0 && elem_bytes[a] <= 16 && (send_total == 0 || d_send[a]) && (recv_capacity == 0 || d_recv[a]);
+    }
+    mine.valid = ok_local ? 1 : 0;
+    std::vector<pcr_hip_xfer_geom> all((size_t)c->world);
+    Rccl* r = nullptr;
+    int prev = -1;
+    PCR_HIP_TRY(hipGetDevice(&prev));
+    if (prev != c->device) PCR_HIP_TRY(hipSetDevice(c->device));
+    struct Restore { int prev, dev; ~Restore() { if (prev != dev) (void)hipSetDevice(prev); } } restore{prev, c->device};
+    if (c->world == 1) all[0] = mine;
+    else {
+        r = rccl();
+        int rc = gather_records(c, r, &mine, all.data(), (size_t)kXferInts, st);
+        if (rc) return rc;
+    }
+    std::vector<uint64_t> send_off((size_t)c->world + 1), recv_cnt((size_t)c->world), recv_off((size_t)c->world + 1);
+    int rc = pcr_hip_comm_xfer_plan(all.data(), c->world, c->rank, send_off.data(), recv_cnt.data(), recv_off.data());
+    if (rc) return rc;                                            // the same verdict on every rank
+    if (h_recv_counts) for (int p = 0; p < c->world; ++p) h_recv_counts[p] = recv_cnt[(size_t)p];
+    // my own group never leaves the device
+    for (int a = 0; a < narrays; ++a) {
+        const size_t eb = (size_t)elem_bytes[a];
+        if (recv_cnt[(size_t)c->rank] > 0)
+            PCR_HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_recv[a]) + recv_off[(size_t)c->rank] * eb,
+                                       static_cast<const char*>(d_send[a]) + send_off[(size_t)c->rank] * eb,
+                                       recv_cnt[(size_t)c->rank] * eb, hipMemcpyDeviceToDevice, st));
+    }
+    if (c->world == 1) return PCR_HIP_OK;
+    ncclResult_t first = ncclSuccess;
+    const char* where = "";
+    auto note = [&](ncclResult_t res, const char* w) { if (res != ncclSuccess && first == ncclSuccess) { first = res; where = w; } };
+    PCR_RCCL_TRY(r, r->GroupStart(), "ncclGroupStart");
+    for (int a = 0; a < narrays; ++a) {
+        const size_t eb = (size_t)elem_bytes[a];
+        for (int p = 0; p < c->world; ++p) {
+            if (p == c->rank) continue;
+            const uint64_t ns = mine.send_counts[p], nr = recv_cnt[(size_t)p];
+            if (ns > 0) {
+                note(r->Send(static_cast<const char*>(d_send[a]) + send_off[(size_t)p] * eb, ns * eb, ncclInt8, p, c->comm, st), "ncclSend");
+                c->bytes_sent += ns * eb;
+            }
+            if (nr > 0) note(r->Recv(static_cast<char*>(d_recv[a]) + recv_off[(size_t)p] * eb, nr * eb, ncclInt8, p, c->comm, st), "ncclRecv");
+        }
+    }
+    note(r->GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess) return rccl_fail(r, first, where);
+    return PCR_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// The verdict on `world` gathered records + this rank's offsets: a pure function, the same on every rank.
+int pcr_hip_comm_xfer_plan(const pcr_hip_xfer_geom* all, int world, int rank, uint64_t* send_offsets, uint64_t* recv_counts,
+                           uint64_t* recv_offsets) {
+    PCR_REQUIRE(all && world >= 1 && world <= PCR_HIP_MAX_ROUTE_PARTS && rank >= 0 && rank < world,
+                "comm_xfer_plan: null records, more than 64 ranks, or rank outside [0, world)");
+    PCR_REQUIRE(send_offsets && recv_counts && recv_offsets, "comm_xfer_plan: null result pointer");
+    auto who = [](int r) { return "rank " + std::to_string(r); };
+    for (int r = 0; r < world; ++r) {
+        const pcr_hip_xfer_geom& g = all[r];
+        if (!g.valid) return fail(PCR_HIP_INVALID_ARGUMENT, "comm transfer: " + who(r) + " was called with invalid arguments (null arrays, "
+                                  "element sizes outside 1..16, more than 8 arrays or 64 ranks); refused on every rank");
+        if (g.narrays != all[0].narrays || g.root != all[0].root)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm transfer: " + who(r) + " brings " + std::to_string(g.narrays) + " arrays for root " +
+                        std::to_string(g.root) + " where rank 0 brings " + std::to_string(all[0].narrays) + " for root " +
+                        std::to_string(all[0].root) + "; refused on every rank");
+        for (int a = 0; a < g.narrays; ++a)
+            if (g.elem_bytes[a] != all[0].elem_bytes[a])
+                return fail(PCR_HIP_INVALID_ARGUMENT, "comm transfer: array " + std::to_string(a) + " has " + std::to_string(g.elem_bytes[a]) +
+                            "-byte elements on " + who(r) + " and " + std::to_string(all[0].elem_bytes[a]) + "-byte elements on rank 0; refused on every rank");
+        if (g.root >= 0)
+            for (int p = 0; p < world; ++p)
+                if (p != g.root && g.send_counts[p] != 0)
+                    return fail(PCR_HIP_INVALID_ARGUMENT, "comm_gatherv: " + who(r) + " sends to " + who(p) + ", which is not the root");
+    }
+    for (int q = 0; q < world; ++q) {
+        uint64_t total = 0;
+        for (int p = 0; p < world; ++p) total += all[p].send_counts[q];
+        if (total > all[q].recv_capacity)
+            return fail(PCR_HIP_INVALID_ARGUMENT, "comm transfer: " + who(q) + " would receive " + std::to_string((unsigned long long)total) +
+                        " elements per array but has room for " + std::to_string((unsigned long long)all[q].recv_capacity) + "; refused on every rank");
+    }
+    uint64_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+        send_offsets[p] = so;
+        so += all[rank].send_counts[p];
+        recv_counts[p] = all[p].send_counts[rank];
+        recv_offsets[p] = ro;
+        ro += recv_counts[p];
+    }
+    send_offsets[world] = so;
+    recv_offsets[world] = ro;
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_comm_alltoall_counts(pcr_hip_comm* c, const uint64_t* h_send_counts, uint64_t* h_recv_counts, pcr_hip_stream s) {
+    PCR_REQUIRE(c && h_send_counts && h_recv_counts, "comm_alltoall_counts: null argument");
+    PCR_REQUIRE(c->world <= PCR_HIP_MAX_ROUTE_PARTS, "comm_alltoall_counts: more than 64 ranks");
+    if (c->world == 1) { h_recv_counts[0] = h_send_counts[0]; return PCR_HIP_OK; }
+    hipStream_t st = static_cast<hipStream_t>(s);
+    int prev = -1;
+    PCR_HIP_TRY(hipGetDevice(&prev));
+    if (prev != c->device) PCR_HIP_TRY(hipSetDevice(c->device));
+    struct Restore { int prev, dev; ~Restore() { if (prev != dev) (void)hipSetDevice(prev); } } restore{prev, c->device};
+    const size_t ints = 2 * (size_t)PCR_HIP_MAX_ROUTE_PARTS;
+    uint64_t mine[PCR_HIP_MAX_ROUTE_PARTS] = {};
+    for (int p = 0; p < c->world; ++p) mine[p] = h_send_counts[p];
+    std::vector<uint64_t> all((size_t)c->world * PCR_HIP_MAX_ROUTE_PARTS);
+    int rc = gather_records(c, rccl(), mine, all.data(), ints, st);
+    if (rc) return rc;
+    for (int p = 0; p < c->world; ++p) h_recv_counts[p] = all[(size_t)p * PCR_HIP_MAX_ROUTE_PARTS + (size_t)c->rank];
+    return PCR_HIP_OK;
+}
+
+int pcr_hip_comm_alltoallv(pcr_hip_comm* c, int narrays, const void* const* d_send, void* const* d_recv, const int32_t* elem_bytes,
+                           const uint64_t* h_send_counts, uint64_t recv_capacity, uint64_t* h_recv_counts, pcr_hip_stream s) {
+    return xfer(c, narrays, d_send, d_recv, elem_bytes, h_send_counts, recv_capacity, h_recv_counts, -1, s, "comm_alltoallv");
+}
+
+int pcr_hip_comm_gatherv(pcr_hip_comm* c, int narrays, const void* const* d_send, void* const* d_recv, const int32_t* elem_bytes,
+                         uint64_t send_count, uint64_t recv_capacity, uint64_t* h_recv_counts, int root, pcr_hip_stream s) {
+    PCR_REQUIRE(c, "comm_gatherv: null communicator");
+    uint64_t counts[PCR_HIP_MAX_ROUTE_PARTS] = {};
+    // (a root outside [0, world) is this rank's invalid argument: announced, refused by everyone)
+    if (root >= 0 && root < c->world && root < PCR_HIP_MAX_ROUTE_PARTS) counts[root] = send_count;
+    return xfer(c, narrays, d_send, d_recv, elem_bytes, counts, c->rank == root ? recv_capacity : 0, h_recv_counts,
+                root >= 0 && root < c->world ? root : c->world /* invalid on purpose */, s, "comm_gatherv");
 }
 
 }  // extern "C"

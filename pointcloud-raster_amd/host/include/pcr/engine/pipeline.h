@@ -1,9 +1,11 @@
 // pcr/engine/pipeline.h -- the public engine API (drop-in for the reference's
 // include/pcr/engine/pipeline.h:20-145): ReductionSpec, ExecutionMode, PipelineConfig,
 // ProgressInfo, Pipeline{create, validate, ingest, finalize, run, set_progress_callback,
-// result, stats}.  Behind it: the MI355X HIP engine (include/pcr_hip.h).  There is no CPU
-// engine in this build: ExecutionMode::CPU, a missing GPU or a failing HIP call are errors,
-// never a silent fallback.
+// result, stats}.  Behind it: the MI355X HIP engine (include/pcr_hip.h) for GPU / Auto / Hybrid,
+// and a host engine for ExecutionMode::CPU and for the cases in which the reference falls back to
+// its CPU mode (no device + gpu_fallback_to_cpu, Auto without a GPU: src/engine/pipeline.cpp:100-131)
+// -- announced on stderr with the reference's own Warning / Info line, visible through engine(),
+// and forbidden altogether by PCR_REQUIRE_GPU_ENGINE=1.
 #pragma once
 
 #include "pcr/core/grid_config.h"
@@ -41,7 +43,7 @@ struct PipelineConfig {
     CRS target_crs;
     bool auto_reproject = true;
 
-    ExecutionMode exec_mode = ExecutionMode::Auto;   // GPU, Auto and Hybrid all run the HIP engine
+    ExecutionMode exec_mode = ExecutionMode::Auto;   // GPU, Auto and Hybrid run the HIP engine; CPU the host engine
 
     // A grid whose accumulation state (4 B per cell and plane, + the finalized bands) exceeds gpu_memory_budget (0 = ~80 %
     // of the free GPU memory) is processed OUT OF CORE: in row bands of whole reference-tile rows, one band's state in HBM at
@@ -55,10 +57,10 @@ struct PipelineConfig {
     size_t gpu_pool_size_bytes = 512 * 1024 * 1024;  // initial scratch arena of the engine
     int cuda_device_id = 0;                          // HIP device ordinal
     bool use_cuda_streams = true;
-    bool gpu_fallback_to_cpu = true;                 // ignored: no CPU engine to fall back to
+    bool gpu_fallback_to_cpu = true;                 // GPU mode without a usable device continues on the host engine (with a Warning)
     bool gpu_require_strict = false;
 
-    size_t cpu_threads = 0;
+    size_t cpu_threads = 0;                          // host engine: OpenMP threads (0 = all cores)
     size_t hybrid_cpu_threads = 0;
 
     std::string state_dir;
@@ -153,6 +155,10 @@ public:
     /// Row-block shards: ORs `d_union` (tiles_x * tiles_y device words: the all-reduced flags of every rank) into this
     /// pipeline's flags on its stream; bands a scatter stored are dropped -- on the device -- only when a flag really changed.
     Status merge_touched(const void* d_union);
+    /// The finished band `band` of the last finalize() in DEVICE memory (own rows x width floats; the device-resident
+    /// result's band, or the device-side copy a host-resident result was made from): what a sharded gather sends.
+    /// nullptr before the first finalize, out of core, or for a band index outside the result.
+    const float* result_band_device(int band) const;
     Status synchronize();
     void* stream_handle() const;                 // the hipStream_t every kernel of this pipeline runs on (may be null)
     // per-kernel HIP-event timing of the scatter kernels (roofline reporting)
@@ -167,13 +173,17 @@ public:
 
     /// True when the grid's state did not fit the device budget and the pipeline sweeps it in row bands (out of core).
     bool out_of_core() const;
+    /// "hip" (the MI355X engine) or "host" (ExecutionMode::CPU, or a fallback the reference would have taken too).
+    const char* engine() const;
 
 private:
     Pipeline() = default;
     struct Impl;
     struct Banded;                       // out-of-core driver: row bands of whole reference-tile rows, one in HBM at a time
+    struct Host;                         // the pipeline on the host engine (host/src/host_pipeline.h)
     std::unique_ptr<Impl> impl_;
     std::unique_ptr<Banded> banded_;
+    std::unique_ptr<Host> host_;
 };
 
 // Why the last Pipeline::create() on this thread returned nullptr.

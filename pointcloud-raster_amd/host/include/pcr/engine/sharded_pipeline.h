@@ -9,8 +9,11 @@
 //     /* carry id to every rank (MPI_Bcast, a file, ...) */
 //     auto sp = ShardedPipeline::create(cfg /* WHOLE grid */, id, rank, world, device);
 //     sp->ingest(cloud);   // any superset of the points whose centre row this rank owns
-//     sp->finalize();      // halo reduce + touched-tile union + local finalize
-//     sp->result();        // rows [row_begin(), row_end()) of every band
+//     sp->ingest_unrouted(shard);   // or: an ARBITRARY shard of the cloud -- its points travel to their owners first
+//     sp->finalize();      // halo reduce + touched-tile union + local finalize (+ ONE GeoTIFF from rank 0 when
+//                          // cfg.output_path is set, as the reference writes one file: src/engine/pipeline.cpp:1351-1361)
+//     sp->result();        // rows [row_begin(), row_end()) of every band: this rank's STRIP
+//     sp->gather(0, &grid);  // the whole grid on one rank (the strips in rank order = row order)
 #pragma once
 
 #include <cstdint>
@@ -41,10 +44,20 @@ public:
     static const std::string& create_error();
 
     Status ingest(const PointCloud& cloud);
+    /// SURVEY section 8e "device-side partition + peer copy": `cloud` is an ARBITRARY shard of the whole cloud (a file chunk
+    /// per rank).  Its points are grouped by owner on the device (pcr_hip_route_count / _scatter), travel to their owners
+    /// (pcr_hip_comm_alltoallv: counts agreed first, one grouped ncclSend / ncclRecv round for x, y and every channel), and
+    /// each rank ingests what it receives.  Collective: every rank calls it once per round, with an empty cloud (count() == 0)
+    /// if it has nothing to contribute.  Channels must be 4 or 8 bytes wide; at most six of them.  `ingested` = points received.
+    Status ingest_unrouted(const PointCloud& cloud, size_t* ingested = nullptr);
     /// The exchange alone (finalize() calls it): apron rows to their owners, touched-tile union.
     Status exchange();
     Status finalize();
     const Grid* result() const { return pipe_->result(); }
+    /// Collective, after finalize(): every rank's strip to `dst_rank` (pcr_hip_comm_gatherv, device to device), where *out
+    /// becomes a host Grid of the WHOLE grid (width x height, the strips' bands); *out stays null on the other ranks.  The
+    /// reference's result() is one grid and it writes one file (src/engine/pipeline.cpp:1175-1186, 1351-1361).
+    Status gather(int dst_rank, std::unique_ptr<Grid>* out);
     Pipeline& pipeline() { return *pipe_; }
     int row_begin() const { return r0_; }
     int row_end() const { return r1_; }
@@ -56,7 +69,9 @@ private:
     ShardedPipeline() = default;
     std::unique_ptr<Pipeline> pipe_;
     ::pcr_hip_comm* comm_ = nullptr;
-    int rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, halo_ = 0, width_ = 0;
+    int rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, halo_ = 0, width_ = 0, height_ = 0, align_ = 1;
+    GridConfig grid_;                 // the WHOLE grid
+    std::string output_path_;         // taken from the configuration: rank 0 writes ONE GeoTIFF at finalize()
     bool tiles_local_ = false;
     bool line_hl_groups_ = false;     // a Line group with a per-point half_length channel: ingest agrees on its reach first
 };

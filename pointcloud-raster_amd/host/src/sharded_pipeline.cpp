@@ -7,6 +7,9 @@
 #include <vector>
 
 #include "buffer.h"
+#include "pcr/core/grid.h"
+#include "pcr/core/point_cloud.h"
+#include "pcr/io/grid_io.h"
 #include "pcr_hip.h"
 
 namespace pcr {
@@ -43,6 +46,13 @@ std::unique_ptr<ShardedPipeline> ShardedPipeline::create(PipelineConfig cfg, con
     cfg.shard_row_begin = blk.first;
     cfg.shard_row_end = blk.second;
     cfg.cuda_device_id = device;
+    sp->grid_ = cfg.grid;
+    sp->height_ = cfg.grid.height;
+    sp->align_ = align;
+    // ONE file for the whole grid, written by rank 0 from the gathered strips (the reference writes one file,
+    // src/engine/pipeline.cpp:1351-1361) -- not a strip per rank under the same name
+    sp->output_path_ = cfg.output_path;
+    cfg.output_path.clear();
     sp->pipe_ = Pipeline::create(cfg);
     if (!sp->pipe_) {
         g_create_error = "ShardedPipeline: " + pipeline_create_error();
@@ -132,7 +142,181 @@ Status ShardedPipeline::exchange() {
 Status ShardedPipeline::finalize() {
     Status s = exchange();
     if (!s.ok()) return s;
-    return pipe_->finalize();
+    if (!(s = pipe_->finalize()).ok()) return s;
+    if (output_path_.empty()) return s;
+    std::unique_ptr<Grid> whole;
+    if (!(s = gather(0, &whole)).ok()) return s;
+    if (rank_ != 0) return s;
+    return write_geotiff(output_path_, *whole, grid_, GeoTiffOptions());
+}
+
+Status ShardedPipeline::gather(int dst_rank, std::unique_ptr<Grid>* out) {
+    if (!out) return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::gather: null result pointer");
+    out->reset();
+    if (dst_rank < 0 || dst_rank >= world_)
+        return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::gather: destination rank outside [0, world)");
+    const Grid* part = pipe_->result();
+    if (!part) return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::gather: finalize() first");
+    const int nb = part->num_bands();
+    if (world_ == 1) {
+        *out = part->to(MemoryLocation::Host);
+        return *out ? Status::success() : Status::error(StatusCode::OutOfMemory, "ShardedPipeline::gather: host allocation failed");
+    }
+    void* stream = pipe_->stream_handle();
+    const uint64_t strip = (uint64_t)(r1_ - r0_) * (uint64_t)width_, whole = (uint64_t)height_ * (uint64_t)width_;
+    const bool root = rank_ == dst_rank;
+    std::unique_ptr<Grid> grid;
+    detail::Buffer landing;
+    // bands per round: up to 8 travel in one group; the landing area on the root is kept below ~4 GB
+    const int per_round = (int)std::max<uint64_t>(1, std::min<uint64_t>(PCR_HIP_MAX_XFER_ARRAYS, ((uint64_t)4 << 30) / std::max<uint64_t>(whole * 4, 1)));
+    Status local = Status::success();           // a local failure is announced through the transfer's own agreement (null arrays)
+    if (root) {
+        std::vector<BandDesc> descs;
+        for (int b = 0; b < nb; ++b) descs.push_back(part->band_desc(b));
+        grid = Grid::create(width_, height_, descs, MemoryLocation::Host);
+        if (!grid) local = Status::error(StatusCode::OutOfMemory, "ShardedPipeline::gather: host allocation of the whole grid failed");
+        else local = landing.allocate((size_t)std::min(per_round, nb) * whole * sizeof(float), MemoryLocation::Device);
+    }
+    for (int b0 = 0; b0 < nb; b0 += per_round) {
+        const int k = std::min(per_round, nb - b0);
+        const void* send[PCR_HIP_MAX_XFER_ARRAYS] = {};
+        void* recv[PCR_HIP_MAX_XFER_ARRAYS] = {};
+        int32_t elem[PCR_HIP_MAX_XFER_ARRAYS] = {};
+        for (int a = 0; a < k; ++a) {
+            send[a] = pipe_->result_band_device(b0 + a);
+            recv[a] = root && local.ok() ? static_cast<float*>(landing.data()) + (size_t)a * whole : nullptr;
+            elem[a] = 4;
+        }
+        uint64_t counts[PCR_HIP_MAX_ROUTE_PARTS] = {};
+        Status s = detail::hip_status(pcr_hip_comm_gatherv(comm_, k, send, recv, elem, strip, root ? whole : 0, counts, dst_rank, stream));
+        if (!s.ok()) return local.ok() ? s : local;
+        if (!root) continue;
+        uint64_t got = 0;
+        for (int p = 0; p < world_; ++p) got += counts[p];
+        if (got != whole)
+            return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::gather: the ranks' strips hold " + std::to_string((unsigned long long)got) +
+                                 " cells, the grid has " + std::to_string((unsigned long long)whole));
+        for (int a = 0; a < k; ++a) {
+            s = detail::hip_status(pcr_hip_memcpy_d2h(grid->band_f32(b0 + a), recv[a], (size_t)whole * sizeof(float), stream));
+            if (!s.ok()) return s;
+        }
+        if (!(s = detail::hip_status(pcr_hip_stream_synchronize(stream))).ok()) return s;     // (the landing area is reused)
+    }
+    if (root) *out = std::move(grid);
+    return Status::success();
+}
+
+Status ShardedPipeline::ingest_unrouted(const PointCloud& cloud_in, size_t* ingested) {
+    if (ingested) *ingested = 0;
+    void* stream = pipe_->stream_handle();
+    // A rank whose own part fails still takes part in every collective of the round (with nothing to send), so that the
+    // others are not left waiting; its error is returned at the end.
+    Status local = Status::success();
+    std::unique_ptr<PointCloud> staged;
+    const PointCloud* cloud = &cloud_in;
+    if (cloud->count() > 0 && cloud->location() != MemoryLocation::Device) {
+        staged = cloud->to(MemoryLocation::Device);
+        if (!staged) local = Status::error(StatusCode::OutOfMemory, "ShardedPipeline::ingest_unrouted: cannot copy the cloud to the device");
+        else cloud = staged.get();
+    }
+    const std::vector<std::string> names = cloud->channel_names();
+    const int narrays = 2 + (int)names.size();
+    if (narrays > PCR_HIP_MAX_ROUTE_ARRAYS)
+        return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::ingest_unrouted: at most six channels are routed in one pass");
+    int32_t elem[PCR_HIP_MAX_ROUTE_ARRAYS] = {8, 8};
+    for (size_t c = 0; c < names.size(); ++c) {
+        elem[2 + c] = (int32_t)data_type_size(cloud->channel(names[c])->dtype);
+        if (elem[2 + c] != 4 && elem[2 + c] != 8)
+            return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::ingest_unrouted: channel " + names[c] + " is not 4 or 8 bytes wide");
+    }
+    const uint64_t n = local.ok() ? cloud->count() : 0;
+    std::vector<int32_t> splits((size_t)world_ + 1);
+    for (int r = 0; r < world_; ++r) splits[(size_t)r] = row_block(r, world_, height_, align_).first;
+    splits[(size_t)world_] = height_;
+    pcr_hip_grid hg{};
+    hg.min_x = grid_.bounds.min_x; hg.min_y = grid_.bounds.min_y; hg.max_x = grid_.bounds.max_x; hg.max_y = grid_.bounds.max_y;
+    hg.cell_size_x = grid_.cell_size_x; hg.cell_size_y = grid_.cell_size_y;
+    hg.width = grid_.width; hg.height = grid_.height; hg.tile_width = grid_.tile_width; hg.tile_height = grid_.tile_height;
+    hg.own_row0 = 0; hg.own_row1 = grid_.height; hg.state_row0 = 0; hg.state_rows = grid_.height;    // the routing sees the whole grid
+
+    // 1. owner of every point, points per owner
+    std::vector<uint64_t> send_counts((size_t)PCR_HIP_MAX_ROUTE_PARTS, 0), recv_counts((size_t)PCR_HIP_MAX_ROUTE_PARTS, 0);
+    detail::Buffer dest, counts, grouped[PCR_HIP_MAX_ROUTE_ARRAYS];
+    if (n > 0 && local.ok()) {
+        local = dest.allocate((size_t)n, MemoryLocation::Device);
+        if (local.ok()) local = counts.allocate(2 * (size_t)world_ * sizeof(uint64_t), MemoryLocation::Device);
+        if (local.ok())
+            local = detail::hip_status(pcr_hip_route_count(&hg, splits.data(), world_, cloud->x(), cloud->y(), nullptr, n,
+                                                           static_cast<uint8_t*>(dest.data()), static_cast<unsigned long long*>(counts.data()), stream));
+        if (local.ok()) local = detail::hip_status(pcr_hip_memcpy_d2h(send_counts.data(), counts.data(), (size_t)world_ * sizeof(uint64_t), stream));
+        if (local.ok()) local = detail::hip_status(pcr_hip_stream_synchronize(stream));
+        if (!local.ok()) std::fill(send_counts.begin(), send_counts.end(), 0);
+    }
+    uint64_t total_send = 0;
+    std::vector<uint64_t> cursors((size_t)world_);
+    for (int p = 0; p < world_; ++p) { cursors[(size_t)p] = total_send; total_send += send_counts[(size_t)p]; }
+    // 2. every array regrouped by owner
+    const void* src[PCR_HIP_MAX_ROUTE_ARRAYS] = {};
+    void* grp[PCR_HIP_MAX_ROUTE_ARRAYS] = {};
+    if (total_send > 0 && local.ok()) {
+        src[0] = cloud->x();
+        src[1] = cloud->y();
+        for (size_t c = 0; c < names.size(); ++c) src[2 + c] = cloud->channel_data(names[c]);
+        for (int a = 0; a < narrays && local.ok(); ++a) {
+            local = grouped[a].allocate((size_t)total_send * (size_t)elem[a], MemoryLocation::Device);
+            grp[a] = grouped[a].data();
+        }
+        unsigned long long* d_cursors = static_cast<unsigned long long*>(counts.data()) + world_;
+        if (local.ok()) local = detail::hip_status(pcr_hip_memcpy_h2d(d_cursors, cursors.data(), (size_t)world_ * sizeof(uint64_t), stream));
+        if (local.ok())
+            local = detail::hip_status(pcr_hip_route_scatter(static_cast<const uint8_t*>(dest.data()), n, world_, d_cursors, narrays, src, grp, elem, stream));
+        if (!local.ok()) { std::fill(send_counts.begin(), send_counts.end(), 0); total_send = 0; }
+    }
+    // 3. the groups travel to their owners
+    uint64_t total_recv = 0;
+    if (world_ > 1) {
+        Status s = detail::hip_status(pcr_hip_comm_alltoall_counts(comm_, send_counts.data(), recv_counts.data(), stream));
+        if (!s.ok()) return local.ok() ? s : local;
+        for (int p = 0; p < world_; ++p) total_recv += recv_counts[(size_t)p];
+    } else {
+        total_recv = total_send;
+    }
+    std::unique_ptr<PointCloud> mine = PointCloud::create((size_t)std::max<uint64_t>(total_recv, 1), MemoryLocation::Device);
+    void* dst[PCR_HIP_MAX_ROUTE_ARRAYS] = {};
+    bool have = mine != nullptr;
+    if (have) {
+        for (size_t c = 0; c < names.size() && have; ++c) have = mine->add_channel(names[c], cloud->channel(names[c])->dtype).ok();
+        if (have) have = mine->resize((size_t)total_recv).ok();
+    }
+    if (have) {
+        dst[0] = mine->x();
+        dst[1] = mine->y();
+        for (size_t c = 0; c < names.size(); ++c) dst[2 + c] = mine->channel_data(names[c]);
+    } else if (local.ok()) {
+        local = Status::error(StatusCode::OutOfMemory, "ShardedPipeline::ingest_unrouted: cannot allocate the routed cloud on the device");
+    }
+    if (world_ > 1) {
+        // (a rank without a landing area announces no room: every rank refuses the round together)
+        Status s = detail::hip_status(pcr_hip_comm_alltoallv(comm_, narrays, grp, dst, elem, send_counts.data(), have ? total_recv : 0,
+                                                             nullptr, stream));
+        if (!s.ok()) return local.ok() ? s : local;
+    } else if (have && total_recv > 0 && local.ok()) {
+        for (int a = 0; a < narrays && local.ok(); ++a)
+            local = detail::hip_status(pcr_hip_memcpy_d2d(dst[a], grp[a], (size_t)total_recv * (size_t)elem[a], stream));
+    }
+    // 4. ingest what arrived (ingest() agrees on the Line reach over the ranks first; a rank that failed locally still joins
+    //    that agreement, with an empty cloud)
+    Status s = Status::success();
+    if (local.ok() && have) {
+        s = ingest(*mine);
+        if (s.ok() && ingested) *ingested = (size_t)total_recv;
+    } else {
+        std::unique_ptr<PointCloud> none = PointCloud::create(1, MemoryLocation::Device);
+        if (none) { (void)none->resize(0); (void)ingest(*none); }
+    }
+    Status sync = pipe_->synchronize();                      // `mine` and the staging buffers are freed on return
+    if (!local.ok()) return local;
+    return s.ok() ? sync : s;
 }
 
 uint64_t ShardedPipeline::bytes_sent() const {

@@ -170,6 +170,8 @@ void bind_engine(py::module_& m) {
         .def("merge_touched", [](Pipeline& p, uintptr_t d_union) {
             raise_if_error(p.merge_touched(reinterpret_cast<const void*>(d_union)));
         }, "OR the all-reduced touched flags of every rank (device words) into this pipeline's flags, on its stream")
+        .def("result_band_device_ptr", [](const Pipeline& p, int band) { return reinterpret_cast<uintptr_t>(p.result_band_device(band)); },
+             "Device address of finished band `band` (own rows x width floats) after finalize(); 0 when there is none")
         .def("synchronize", [](Pipeline& p) { raise_if_error(p.synchronize()); })
         .def("stream_ptr", [](const Pipeline& p) { return reinterpret_cast<uintptr_t>(p.stream_handle()); })
         .def("profile_enable", &Pipeline::profile_enable, py::arg("on"), py::arg("only_kernel") = "")
@@ -192,6 +194,8 @@ void bind_engine(py::module_& m) {
             d["bands_with_scatter"] = s.bands_with_scatter;
             return d;
         })
+        .def("engine", [](const Pipeline& p) { return std::string(p.engine()); },
+             "'hip' (the MI355X engine) or 'host' (ExecutionMode.CPU, or a fallback the reference would have taken too)")
         .def("out_of_core", &Pipeline::out_of_core,
              "True when the grid's state exceeds gpu_memory_budget and the pipeline sweeps it in row bands of whole reference-tile rows");
 
@@ -218,6 +222,16 @@ void bind_engine(py::module_& m) {
         .def("ingest", [](ShardedPipeline& p, const PointCloud& c) { raise_if_error(p.ingest(c)); })
         .def("exchange", [](ShardedPipeline& p) { raise_if_error(p.exchange()); })
         .def("finalize", [](ShardedPipeline& p) { raise_if_error(p.finalize()); })
+        .def("ingest_unrouted", [](ShardedPipeline& p, const PointCloud& c) {
+            size_t got = 0;
+            raise_if_error(p.ingest_unrouted(c, &got));
+            return got;
+        }, "An arbitrary shard of the cloud: partitioned by owner on the device, exchanged (pcr_hip_comm_alltoallv), ingested; -> points received")
+        .def("gather", [](ShardedPipeline& p, int dst_rank) {
+            std::unique_ptr<Grid> g;
+            raise_if_error(p.gather(dst_rank, &g));
+            return g;
+        }, py::arg("dst_rank") = 0, "Collective, after finalize(): the whole grid as one host Grid on dst_rank, None elsewhere")
         .def("result", &ShardedPipeline::result, py::return_value_policy::reference_internal)
         .def("pipeline", &ShardedPipeline::pipeline, py::return_value_policy::reference_internal)
         .def("row_begin", &ShardedPipeline::row_begin)

@@ -66,6 +66,11 @@ class HaloGeom(C.Structure):
                                          "kinds", "valid", "reserved_")]
 
 
+class XferGeom(C.Structure):
+    _fields_ = [("narrays", C.c_int32), ("elem_bytes", C.c_int32 * 8), ("root", C.c_int32), ("valid", C.c_int32),
+                ("reserved_", C.c_int32), ("recv_capacity", C.c_uint64), ("send_counts", C.c_uint64 * 64)]
+
+
 SYMBOLS = {
     "pcr_hip_last_error": None,
     "pcr_hip_abi_version": [],
@@ -113,6 +118,12 @@ SYMBOLS = {
     "pcr_hip_comm_allreduce_max_u32": [_VP, _VP, C.c_int, _VP],
     "pcr_hip_comm_allreduce_sum_f64": [_VP, _VP, C.c_int, _VP],
     "pcr_hip_comm_stats": [_VP, C.POINTER(_U64), C.POINTER(_U64)],
+    "pcr_hip_comm_alltoall_counts": [_VP, C.POINTER(_U64), C.POINTER(_U64), _VP],
+    "pcr_hip_comm_alltoallv": [_VP, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32), C.POINTER(_U64), _U64,
+                               C.POINTER(_U64), _VP],
+    "pcr_hip_comm_gatherv": [_VP, C.c_int, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32), _U64, _U64, C.POINTER(_U64),
+                             C.c_int, _VP],
+    "pcr_hip_comm_xfer_plan": [C.POINTER(XferGeom), C.c_int, C.c_int, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)],
     "pcr_hip_state_floats": [C.c_int, C.POINTER(C.c_int)],
     "pcr_hip_plane_fill": [_VP, C.c_float, _I64, _VP],
     "pcr_hip_state_init": [C.c_int, _VP, _I64, _VP],

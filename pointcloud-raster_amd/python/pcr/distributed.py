@@ -196,21 +196,52 @@ def partition_cloud(cloud, grid_cfg, blocks, stream=0):
     return h_counts, grouped
 
 
-def route_cloud(cloud, grid_cfg, blocks, rank, world, group=None, stream=0):
+def route_cloud(cloud, grid_cfg, blocks, rank, world, group=None, stream=0, comm=None):
     """Routes an arbitrary shard of the cloud to the owners of the row blocks: device-side partition, then one
     all-to-all per array (RCCL over xGMI; gloo stages through host memory in rehearsals).  Collective: every rank
-    calls it.  Returns a device-resident pcr.PointCloud holding exactly the points whose centre row this rank owns."""
+    calls it.  Returns a device-resident pcr.PointCloud holding exactly the points whose centre row this rank owns.
+    comm: a pcr_hip_comm handle -- the groups then travel through the library's own pcr_hip_comm_alltoallv (counts agreed
+    first, x, y and every channel in ONE grouped ncclSend / ncclRecv round) instead of torch.distributed."""
     import pcr
     # one stream for the partition kernels, the torch allocations and the collectives (see partition_cloud)
     ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream else torch.cuda.stream(torch.cuda.current_stream())
     with ctx:
         return _route_cloud_on_current_stream(cloud, grid_cfg, blocks, rank, world, group,
-                                              stream or torch.cuda.current_stream().cuda_stream)
+                                              stream or torch.cuda.current_stream().cuda_stream, comm)
 
 
-def _route_cloud_on_current_stream(cloud, grid_cfg, blocks, rank, world, group, stream):
+def _alltoallv_native(comm, cloud, counts, grouped, world, stream):
+    """pcr_hip_comm_alltoall_counts + pcr_hip_comm_alltoallv (include/pcr_hip.h) on the partition's grouped arrays."""
+    import ctypes as C
+    import pcr
+    from . import _cabi as A
+    L = A.lib()
+    send = (C.c_uint64 * 64)(*counts)
+    recv = (C.c_uint64 * 64)()
+    A.check(L.pcr_hip_comm_alltoall_counts(comm, send, recv, stream))
+    total = sum(int(recv[p]) for p in range(world))
+    out = pcr.PointCloud.create(max(total, 1), pcr.MemoryLocation.Device)
+    if out is not None:
+        for name in cloud.channel_names():
+            out.add_channel(name, cloud.channel(name).dtype)
+        out.resize(total)
+    k = len(grouped)
+    optrs = out.device_ptrs() if out is not None else {}
+    srcs = (C.c_void_p * k)(*[t.data_ptr() if t.numel() else None for t, _ in grouped.values()])
+    dsts = (C.c_void_p * k)(*[optrs.get(name) if total else None for name in grouped])
+    elems = (C.c_int32 * k)(*[_ELEM_BYTES[kind] for _, kind in grouped.values()])
+    # (a rank that could not allocate announces no room: every rank refuses the round together)
+    A.check(L.pcr_hip_comm_alltoallv(comm, k, srcs, dsts, elems, send, total if out is not None else 0, None, stream))
+    if out is None:
+        raise MemoryError("route_cloud: cannot allocate the routed cloud on the device")
+    return out
+
+
+def _route_cloud_on_current_stream(cloud, grid_cfg, blocks, rank, world, group, stream, comm=None):
     import pcr
     counts, grouped = partition_cloud(cloud, grid_cfg, blocks, stream)
+    if comm is not None:
+        return _alltoallv_native(comm, cloud, counts, grouped, world, stream)
     stage = dist.get_backend(group) == "gloo"
     dev = torch.device("cuda", torch.cuda.current_device())
     send = torch.tensor(counts, dtype=torch.int64, device="cpu" if stage else dev)
@@ -280,6 +311,9 @@ class ShardedPipeline:
         self.blocks = [row_block(r, world, cfg.grid.height, align) for r in range(world)]
         self.own = self.blocks[rank]
         cfg.shard_row_begin, cfg.shard_row_end = self.own
+        # ONE file for the whole grid, written by rank 0 from the gathered strips (the reference writes one file,
+        # src/engine/pipeline.cpp:1351-1361) -- not a strip per rank under the same name
+        self.output_path, cfg.output_path = cfg.output_path, ""
         if device_id is not None:
             cfg.cuda_device_id = device_id
         self.pipe = pcr.Pipeline.create(cfg)
@@ -392,7 +426,7 @@ class ShardedPipeline:
             cloud = cloud.to_device()
         ptr, ctx = self._engine_stream()
         with ctx:
-            mine = route_cloud(cloud, self.grid, self.blocks, self.rank, self.world, self.group, ptr)
+            mine = route_cloud(cloud, self.grid, self.blocks, self.rank, self.world, self.group, ptr, comm=self._comm)
             if not ptr:
                 torch.cuda.current_stream().synchronize()
         self._agree_line_reach(mine)         # after routing: every rank asks about the points it will really ingest
@@ -512,10 +546,91 @@ class ShardedPipeline:
         """exchange + local finalize.  wait=False: Pipeline.finalize_async (a device-resident result is complete after
         pipe.synchronize() / a device synchronisation)."""
         self.exchange(timed)
-        if wait:
+        if wait or self.output_path:
             self.pipe.finalize()
         else:
             self.pipe.finalize_async()
+        if self.output_path:
+            import pcr
+            whole = self.gather(0)
+            if self.rank == 0:
+                pcr.write_geotiff(self.output_path, whole, self.grid)
 
     def result(self):
+        """This rank's STRIP: rows [own[0], own[1]) of every band.  gather() assembles the whole grid on one rank."""
         return self.pipe.result()
+
+    def gather(self, dst_rank=0):
+        """Collective, after finalize(): every rank's strip travels to `dst_rank`, which returns ONE host pcr.Grid of the whole
+        grid (the strips in rank order are the grid's rows in order); the other ranks return None.  The reference's result()
+        is one grid (src/engine/pipeline.cpp:1175-1186).  comm = "native": pcr_hip_comm_gatherv, device to device (up to
+        eight bands per grouped round); comm = "torch": send / recv of the bands (nccl: from HBM; gloo: staged through host
+        memory)."""
+        import numpy as np
+        import pcr
+        res = self.pipe.result()
+        if res is None:
+            raise RuntimeError("ShardedPipeline.gather: finalize() first")
+        if not 0 <= dst_rank < self.world:
+            raise ValueError("ShardedPipeline.gather: destination rank outside [0, world)")
+        nb, W, H = res.num_bands(), self.width, self.grid.height
+        root = self.rank == dst_rank
+        rows = self.own[1] - self.own[0]
+        on_device = res.location() == pcr.MemoryLocation.Device
+
+        def strip_device(b):                       # this rank's band b as a device tensor (zero-copy)
+            ptr = self.pipe.result_band_device_ptr(b)
+            return torch.as_tensor(pcr.DeviceArrayView(ptr, (rows, W), "<f4", owner=self.pipe), device="cuda")
+
+        def strip_host(b):
+            return strip_device(b).cpu() if on_device else torch.from_numpy(np.array(res.band_array(b)))
+
+        whole = pcr.Grid.create(W, H, [res.band_desc(b) for b in range(nb)]) if root else None
+        if self.world == 1:
+            for b in range(nb):
+                whole.set_band_array(b, strip_host(b).numpy())
+            return whole
+        if self._comm is not None:
+            import ctypes as C
+            from . import _cabi as A
+            L = A.lib()
+            stream, ctx = self._engine_stream()
+            per_round = max(1, min(8, (4 << 30) // max(H * W * 4, 1)))
+            with ctx:
+                for b0 in range(0, nb, per_round):
+                    k = min(per_round, nb - b0)
+                    land = torch.empty((k, H, W), dtype=torch.float32, device="cuda") if root else None
+                    strips = [strip_device(b0 + a) for a in range(k)]
+                    srcs = (C.c_void_p * k)(*[t.data_ptr() for t in strips])
+                    dsts = (C.c_void_p * k)(*[land[a].data_ptr() if root else None for a in range(k)])
+                    elems = (C.c_int32 * k)(*([4] * k))
+                    A.check(L.pcr_hip_comm_gatherv(self._comm, k, srcs, dsts, elems, rows * W, H * W if root else 0, None,
+                                                   dst_rank, stream))
+                    if root:
+                        host = land.cpu()                    # (on this stream: after the receives)
+                        for a in range(k):
+                            whole.set_band_array(b0 + a, host[a].numpy())
+                if not stream:
+                    torch.cuda.current_stream().synchronize()
+            return whole
+        stage = dist.get_backend(self.group) == "gloo"
+        if stage and not on_device:
+            import contextlib
+            ctx = contextlib.nullcontext()           # host bands over gloo: no device in the path at all
+        else:
+            _, ctx = self._engine_stream()
+        with ctx:
+            for b in range(nb):
+                mine = strip_host(b) if stage else strip_device(b)
+                if root:
+                    full = torch.empty((H, W), dtype=torch.float32, device="cpu" if stage else "cuda")
+                    ops = [dist.P2POp(dist.irecv, full[b0:b1], r, self.group)
+                           for r, (b0, b1) in enumerate(self.blocks) if r != self.rank and b1 > b0]
+                    for req in (dist.batch_isend_irecv(ops) if ops else []):
+                        req.wait()
+                    full[self.own[0]:self.own[1]] = mine
+                    whole.set_band_array(b, full.cpu().numpy())
+                elif rows > 0:
+                    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), dst_rank, self.group)]):
+                        req.wait()
+        return whole

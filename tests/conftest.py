@@ -18,6 +18,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # A run that contains GPU tests must never pass on the host engine: a GPU pipeline that cannot get its device fails at
+    # create instead of falling back as the reference would (Pipeline::create, PCR_REQUIRE_GPU_ENGINE).
+    if "not gpu" not in (config.getoption("-m") or "") and any(item.get_closest_marker("gpu") for item in items):
+        os.environ.setdefault("PCR_REQUIRE_GPU_ENGINE", "1")
+
+
 def _denan(v):
     if isinstance(v, list):
         return [_denan(a) for a in v]

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f"{n} declared in include/pcr_hip.h but not exported"
     # and the ctypes table covers exactly the header
     assert sorted(A.SYMBOLS) == names
-    assert L.pcr_hip_abi_version() == 4
+    assert L.pcr_hip_abi_version() == 5
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -67,4 +67,4 @@ def test_header_is_plain_c_and_links(tmp_path):
                     str(src), "-o", str(exe), "-L", lib_dir, "-lpcr_hip", f"-Wl,-rpath,{lib_dir}"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "abi 4" in out.stdout
+    assert "abi 5" in out.stdout

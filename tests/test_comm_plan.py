@@ -179,3 +179,83 @@ os._exit(0)
     assert out.returncode == 0, out.stdout + out.stderr
     ok, rc, msg = out.stdout.strip().split(" ", 2)
     assert ok == "0" and rc != "0" and "two copies of RCCL" in msg, out.stdout
+
+
+# ---- the variable-size transfers (pcr_hip_comm_alltoallv / _gatherv): the same discipline, the same kind of test ----
+
+def xfer_records(A, matrix, elem=(8, 8, 4), root=-1, capacity=None, edit=None):
+    """Records of `world` ranks for the send-count matrix[src][dst]; capacity defaults to exactly what each rank receives."""
+    world = len(matrix)
+    arr = (A.XferGeom * world)()
+    for r in range(world):
+        g = arr[r]
+        g.narrays, g.root, g.valid = len(elem), root, 1
+        for a, e in enumerate(elem):
+            g.elem_bytes[a] = e
+        for p in range(world):
+            g.send_counts[p] = matrix[r][p]
+        g.recv_capacity = sum(matrix[p][r] for p in range(world)) if capacity is None else capacity[r]
+    if edit:
+        edit(arr)
+    return arr
+
+
+def xfer_plan_all(A, arr):
+    L = A.lib()
+    world = len(arr)
+    out = []
+    for r in range(world):
+        so, rc_, ro = (C.c_uint64 * (world + 1))(), (C.c_uint64 * world)(), (C.c_uint64 * (world + 1))()
+        rc = L.pcr_hip_comm_xfer_plan(arr, world, r, so, rc_, ro)
+        out.append((rc, L.pcr_hip_last_error().decode(), list(so), list(rc_), list(ro)))
+    return out
+
+
+def test_alltoallv_plan_every_send_has_its_receive():
+    A = load_cabi()
+    import random
+    rnd = random.Random(5)
+    for world in (1, 2, 3, 8):
+        m = [[rnd.randrange(0, 1000) if rnd.random() < 0.8 else 0 for _ in range(world)] for _ in range(world)]
+        res = xfer_plan_all(A, xfer_records(A, m))
+        assert all(rc == 0 for rc, *_ in res), res
+        for r in range(world):
+            _, _, so, rcnt, ro = res[r]
+            assert rcnt == [m[p][r] for p in range(world)]                       # what I receive from p is what p sends me
+            assert so == [sum(m[r][:p]) for p in range(world + 1)]               # my groups lie in rank order
+            assert ro == [sum(rcnt[:p]) for p in range(world + 1)]
+
+
+def test_alltoallv_plan_refuses_on_every_rank_or_on_none():
+    A = load_cabi()
+    m = [[5, 7, 0], [1, 0, 9], [4, 4, 4]]
+    cases = {
+        "a rank without room": dict(capacity=[10, 11, 12]),                       # rank 2 receives 13
+        "element sizes differ": dict(edit=lambda a: a[1].elem_bytes.__setitem__(2, 8)),
+        "array counts differ": dict(edit=lambda a: setattr(a[2], "narrays", 2)),
+        "one rank gathers, the others exchange": dict(edit=lambda a: setattr(a[0], "root", 0)),
+        "a rank with invalid arguments": dict(edit=lambda a: setattr(a[1], "valid", 0)),
+    }
+    for what, kw in cases.items():
+        res = xfer_plan_all(A, xfer_records(A, m, **kw))
+        assert all(rc == 1 for rc, *_ in res), (what, res)
+        assert len({msg for _, msg, *_ in res}) == 1, (what, res)               # the same message everywhere
+
+
+def test_gatherv_plan_strips_land_in_rank_order_on_the_root():
+    A = load_cabi()
+    world, root = 4, 2
+    strips = [2048 * 64, 2048 * 64, 2000 * 64, 100 * 64]
+    m = [[strips[r] if p == root else 0 for p in range(world)] for r in range(world)]
+    res = xfer_plan_all(A, xfer_records(A, m, elem=(4, 4), root=root, capacity=[0, 0, sum(strips), 0]))
+    assert all(rc == 0 for rc, *_ in res), res
+    assert res[root][3] == strips and res[root][4] == [sum(strips[:p]) for p in range(world + 1)]
+    for r in range(world):
+        if r != root:
+            assert res[r][3] == [0] * world
+    # somebody sends to a rank that is not the root / the root has too little room: everyone refuses
+    bad = xfer_plan_all(A, xfer_records(A, m, elem=(4, 4), root=root, capacity=[0, 0, sum(strips), 0],
+                                        edit=lambda a: a[1].send_counts.__setitem__(0, 3)))
+    assert all(rc == 1 and "not the root" in msg for rc, msg, *_ in bad), bad
+    small = xfer_plan_all(A, xfer_records(A, m, elem=(4, 4), root=root, capacity=[0, 0, sum(strips) - 1, 0]))
+    assert all(rc == 1 and "has room for" in msg for rc, msg, *_ in small), small

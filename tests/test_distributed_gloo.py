@@ -188,3 +188,70 @@ def test_line_reach_is_agreed_before_anything_is_accumulated(tmp_path):
     for r in range(2):
         log = eval((tmp_path / f"reach{r}.txt").read_text())
         assert log == [("refused", 0, True), ("ok", 1)], (r, log)
+
+
+class _StripPipe:
+    """Stands in for a finalized device pipeline: result() is this rank's strip as a host pcr.Grid."""
+
+    def __init__(self, grid):
+        self._grid = grid
+
+    def result(self):
+        return self._grid
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+    import pcr
+    import pcr_oracle_py as O
+    from pcr.distributed import ShardedPipeline, row_block
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, H = 48, 100
+        og = O.make_grid((0, 0, W, H))
+        rng = np.random.default_rng(8)
+        x, y = rng.uniform(0, W, 3000), rng.uniform(0, H, 3000)
+        v = rng.uniform(0, 1, 3000).astype(np.float32)
+        bands = [O.run(og, O.SUM, x, y, v), O.run(og, O.COUNT, x, y, v)]
+        sp = ShardedPipeline.__new__(ShardedPipeline)
+        sp.world, sp.rank, sp.group, sp._comm = world, rank, dist.group.WORLD, None
+        sp.blocks = [row_block(r, world, H) for r in range(world)]
+        sp.own = sp.blocks[rank]
+        sp.width = W
+        gc = pcr.GridConfig()
+        gc.bounds = pcr.BBox(0.0, 0.0, float(W), float(H))
+        gc.compute_dimensions()
+        sp.grid = gc
+        descs = []
+        for name in ("value_0", "value_5"):
+            d = pcr.BandDesc()
+            d.name = name
+            descs.append(d)
+        r0, r1 = sp.own
+        strip = pcr.Grid.create(W, r1 - r0, descs)
+        for b in range(2):
+            strip.set_band_array(b, bands[b][r0:r1])
+        sp.pipe = _StripPipe(strip)
+        for dst in (0, world - 1):
+            whole = sp.gather(dst)
+            assert (whole is not None) == (rank == dst)
+            if whole is not None:
+                assert (whole.cols(), whole.rows(), whole.num_bands()) == (W, H, 2) and whole.band_desc(1).name == "value_5"
+                np.savez(os.path.join(out_dir, f"gather{dst}.npz"), b0=np.array(whole.band_array(0)), b1=np.array(whole.band_array(1)),
+                         w0=bands[0], w1=bands[1])
+        sp.pipe = None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_assembles_the_strips_into_one_grid(world, tmp_path):
+    """ShardedPipeline.gather over gloo: the ranks' strips (34 / 33 / 33 rows at world 3) land in row order on the chosen rank,
+    bit for bit the unsharded band (the reference's result() is one grid: src/engine/pipeline.cpp:1175-1186)."""
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for dst in (0, world - 1):
+        d = np.load(tmp_path / f"gather{dst}.npz")
+        assert np.array_equal(d["b0"], d["w0"], equal_nan=True) and np.array_equal(d["b1"], d["w1"], equal_nan=True)

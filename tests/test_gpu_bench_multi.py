@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, launcher=True):
+def _run(extra, launcher=True, ranks=2):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"] + extra
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--backend", "gloo", "--same-device"] + extra
     if launcher:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + tail
     else:
         cmd = [sys.executable] + tail          # the driver's form: bench.py starts its own ranks as a child process
@@ -52,13 +52,16 @@ def test_default_multi_gpu_bench_is_c5_strong_scaling_with_live_exchange():
     _check_selfcheck(r)
 
 
-def _check_selfcheck(r):
+def _check_selfcheck(r, ranks=2):
     sc = r["selfcheck"]
     assert sc["ok"] is True, sc
     assert sc["points_valid_all_ranks"] == sc["points_total"] == r["config"]["points_total"]
     assert sc["gauss_planes"] == 2 and sc["gauss_max_rel_diff"] <= 2e-6
     assert all(v > 0 for v in sc["gauss_halo_rows_sum_before_exchange"])        # the halo rows really carried weight
-    assert r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo"
+    # finalized again, then ingested again: nothing counted twice
+    assert sc["refinalize_owned_rows_unchanged"] is True and all(v == 0 for v in sc["refinalize_halo_rows_sum"])
+    assert sc["second_ingest_max_rel_diff_vs_twice"] <= 4e-6
+    assert r["config"]["world_size"] == ranks and r["config"]["backend"] == "gloo"
 
 
 def test_plain_python_bench_gpus_2_launches_its_own_ranks_and_checks_the_exchange():
@@ -72,3 +75,21 @@ def test_weak_flag_keeps_round_one_shape_without_collectives():
     r = _run(["--weak", "--grid", "1024", "--points", "1000000"])
     assert r["scaling"] == "weak" and r["config"]["grid"] == "1024x2048"
     assert r["config"]["tiles_local"] is False or r["config"]["collectives_per_step"]["p2p_messages"] == 0
+
+
+def test_the_eight_rank_geometry_with_the_five_ranks_a_one_gpu_box_admits():
+    """BASELINE configs[4] at N = 8: 16384 columns, 2048-row blocks that cut the 4096-row reference tiles, halo 4, inner ranks
+    with two neighbours.  A one-GPU box admits SIX processes on its card and this test runner is one of them, so the same
+    blocks are instantiated as five ranks on a 16384 x 10240 grid (blocks 0|1 and 2|3 share a tile row and exchange; 1|2 and
+    3|4 meet on tile boundaries -- exactly the alternation the 8-rank run has; ranks 1, 2, 3 have two neighbours), through the
+    driver's launcher path: the run must validate itself."""
+    r = _run(["--grid", "16384", "--height", "10240", "--points", "1500000"], launcher=False, ranks=5)
+    assert r["n_gpus"] == 5 and r["scaling"] == "strong"
+    c = r["config"]
+    assert c["grid"] == "16384x10240" and c["rows_per_gpu"] == 2048 and c["tiles_local"] is False
+    assert c["collectives_per_step"] == {"p2p_messages": 0, "all_reduces": 1}
+    g1 = r["per_glyph"]["gauss1"]
+    assert g1["exchange"]["halo_rows"] == 4
+    assert g1["exchange"]["collectives_per_step"]["p2p_messages"] == 4          # rank 0: one neighbour, two planes, send + receive
+    assert g1["exchange"]["halo_bytes_sent_per_step"] == 2 * 4 * 16384 * 4
+    _check_selfcheck(r, ranks=5)

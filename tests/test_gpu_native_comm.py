@@ -55,6 +55,37 @@ except A.PcrHipError:
 words = A.DeviceBuffer.from_numpy(np.arange(4, dtype=np.uint32))
 A.check(L.pcr_hip_comm_allreduce_max_u32(comm, words.ptr, 4, None))          # world 1: identity
 assert (words.to_numpy(np.uint32, 4) == np.arange(4, dtype=np.uint32)).all()
+# the variable-size transfers at world 1: a rank's own group is a device-to-device copy, the agreement is still passed
+x = np.arange(1000, dtype=np.float64)
+v = np.arange(1000, dtype=np.float32) * 0.5
+sx, sv = A.DeviceBuffer.from_numpy(x), A.DeviceBuffer.from_numpy(v)
+rx, rv = A.DeviceBuffer.from_numpy(np.zeros(1200, np.float64)), A.DeviceBuffer.from_numpy(np.zeros(1200, np.float32))
+srcs, dsts = (C.c_void_p * 2)(sx.ptr.value, sv.ptr.value), (C.c_void_p * 2)(rx.ptr.value, rv.ptr.value)
+elems = (C.c_int32 * 2)(8, 4)
+send, recv = (C.c_uint64 * 64)(1000), (C.c_uint64 * 64)()
+A.check(L.pcr_hip_comm_alltoall_counts(comm, send, recv, None))
+assert recv[0] == 1000
+recv[0] = 0
+A.check(L.pcr_hip_comm_alltoallv(comm, 2, srcs, dsts, elems, send, 1200, recv, None))
+A.check(L.pcr_hip_stream_synchronize(None))
+assert recv[0] == 1000 and (rx.to_numpy(np.float64, 1000) == x).all() and (rv.to_numpy(np.float32, 1000) == v).all()
+for what, args in (("no room", (2, srcs, dsts, elems, send, 999, recv)), ("9 arrays", (9, srcs, dsts, elems, send, 1200, recv))):
+    try:
+        A.check(L.pcr_hip_comm_alltoallv(comm, *args, None))
+        raise SystemExit("alltoallv accepted: " + what)
+    except A.PcrHipError:
+        pass
+rx2 = A.DeviceBuffer.from_numpy(np.zeros(1000, np.float64))
+A.check(L.pcr_hip_comm_gatherv(comm, 1, (C.c_void_p * 1)(sx.ptr.value), (C.c_void_p * 1)(rx2.ptr.value), (C.c_int32 * 1)(8),
+                               1000, 1000, recv, 0, None))
+A.check(L.pcr_hip_stream_synchronize(None))
+assert (rx2.to_numpy(np.float64, 1000) == x).all()
+try:
+    A.check(L.pcr_hip_comm_gatherv(comm, 1, (C.c_void_p * 1)(sx.ptr.value), (C.c_void_p * 1)(rx2.ptr.value), (C.c_int32 * 1)(8),
+                                   1000, 1000, recv, 3, None))
+    raise SystemExit("gatherv accepted root 3 of 1")
+except A.PcrHipError:
+    pass
 A.check(L.pcr_hip_comm_destroy(comm))
 print("world-one comm ok")
 """
@@ -114,14 +145,32 @@ got = np.array(res.band_array(0)).astype(np.float64)
 m = ~np.isnan(got) & ~np.isnan(exact)
 assert (np.isnan(got) != np.isnan(exact)).sum() <= 4
 assert (np.abs(got[m] - exact[m]) <= 1e-4 * np.maximum(1e-3, np.abs(exact[m]))).all()
+whole = sp.gather(0)
+assert whole is not None and np.array_equal(np.array(whole.band_array(1)), np.array(res.band_array(1)), equal_nan=True)
+del sp
+# an UNROUTED cloud through the C++ pipeline: partitioned by owner on the device (points outside the grid dropped there), ingested
+x2 = np.concatenate([x, rng.uniform(-50, -1, 500)])             # 500 points outside the grid
+y2 = np.concatenate([y, rng.uniform(1, G - 1, 500)])
+v2 = np.concatenate([v, np.ones(500, np.float32)])
+cfg.output_path = os.path.join(sys.argv[2], "one.tif")
+sp = pcr.NativeShardedPipeline.create(cfg, ident, 0, 1, 0)
+cloud = pcr.PointCloud.create(n + 500)
+cloud.set_x_array(x2)
+cloud.set_y_array(y2)
+cloud.add_channel("value", pcr.DataType.Float32)
+cloud.set_channel_array_f32("value", v2)
+assert sp.ingest_unrouted(cloud) == n                           # a host cloud: staged, partitioned, the 500 strays dropped
+sp.finalize()
+assert np.array_equal(np.array(sp.result().band_array(1)), O.run(og, O.COUNT, x, y, v), equal_nan=True)
+assert np.array_equal(np.array(pcr.read_geotiff_band(cfg.output_path, 1)), np.array(sp.result().band_array(1)), equal_nan=True)
 del sp
 print("sharded world-one ok")
 """
 
 
-def test_native_sharded_pipeline_world_one_matches_oracle():
+def test_native_sharded_pipeline_world_one_matches_oracle(tmp_path):
     """The C++ ShardedPipeline (pcr.NativeShardedPipeline) at world 1: id from RCCL, no exchange, the unsharded result."""
-    assert "sharded world-one ok" in _run_child(_SHARDED_WORLD_ONE)
+    assert "sharded world-one ok" in _run_child(_SHARDED_WORLD_ONE, str(tmp_path))
 
 
 def _two_rank_worker(rank, port, out_dir):

@@ -202,7 +202,10 @@ def _worker_twice(rank, world, port, out_dir, comm):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sp = ShardedPipeline(_twice_cfg(pcr), rank, world, device_id=0, comm=comm)
+        cfg = _twice_cfg(pcr)
+        cfg.output_path = os.path.join(out_dir, "whole.tif")        # ONE file, written by rank 0 from the gathered strips
+        cfg.result_location = pcr.MemoryLocation.Device if rank == 1 else pcr.MemoryLocation.Host
+        sp = ShardedPipeline(cfg, rank, world, device_id=0, comm=comm)
         out = {"own": np.array(sp.own), "halo": sp.halo}
         for k in range(3):                          # ingest -> finalize, three times on ONE pipeline
             x, y, v, d = _twice_inputs(k)
@@ -218,8 +221,15 @@ def _worker_twice(rank, world, port, out_dir, comm):
             if k == 1:
                 sp.finalize()                       # a finalize with nothing new in between changes nothing either
             res = sp.result()
+            if res.location() == pcr.MemoryLocation.Device:
+                res = res.to_host()
             for b in range(4):
                 out[f"k{k}b{b}"] = np.array(res.band_array(b))
+        whole = sp.gather(1)                        # the strips to the LAST rank: one grid
+        assert (whole is not None) == (rank == 1)
+        if whole is not None:
+            for b in range(4):
+                out[f"whole{b}"] = np.array(whole.band_array(b))
         np.savez(os.path.join(out_dir, f"t{rank}.npz"), **out)
         sp.close()
     finally:
@@ -257,3 +267,11 @@ def test_two_rank_pipeline_refinalizes_without_counting_the_halo_twice(tmp_path)
             assert np.array_equal(np.isnan(got), np.isnan(w)), f"finalize {k}, band {b}: NaN mask"
             m = ~np.isnan(w)
             assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"finalize {k}, band {b}"
+    # gather: the strips of the last finalize as ONE grid on rank 1; output_path: ONE GeoTIFF of the whole grid from rank 0
+    import pcr
+    w, h, nb, _crs, _bounds = pcr.read_geotiff_info(str(tmp_path / "whole.tif"))
+    assert (w, h, nb) == (G_W, G_H, 4)
+    for b in range(4):
+        strips = np.vstack([parts[0][f"k2b{b}"], parts[1][f"k2b{b}"]])
+        assert np.array_equal(parts[1][f"whole{b}"], strips, equal_nan=True), f"gather, band {b}"
+        assert np.array_equal(np.array(pcr.read_geotiff_band(str(tmp_path / "whole.tif"), b)), strips, equal_nan=True), f"GeoTIFF, band {b}"
