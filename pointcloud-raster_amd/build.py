@@ -69,6 +69,8 @@ def build_host(force=False):
     for base, _, files in os.walk(os.path.join(HERE, "host", "include")):
         hdrs += [os.path.join(base, f) for f in files]
     hdrs.append(os.path.join(ROOT, "include", "pcr_hip.h"))
+    for d in src_dirs:                                   # the internal headers next to the sources
+        hdrs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")]
     hdr_t = newest(hdrs)
     cxx = os.environ.get("CXX", "g++")
     flags = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-fopenmp", "-ffp-contract=off",

@@ -173,6 +173,9 @@ public:
 
     /// True when the grid's state did not fit the device budget and the pipeline sweeps it in row bands (out of core).
     bool out_of_core() const;
+    /// Out of core: the pipeline's own directory of evicted bands -- `.pcrt` tile files in the reference's layout, removed with
+    /// the pipeline (save_state() writes checkpoints that stay).  Empty otherwise.
+    std::string spill_dir() const;
     /// "hip" (the MI355X engine) or "host" (ExecutionMode::CPU, or a fallback the reference would have taken too).
     const char* engine() const;
 

@@ -856,18 +856,23 @@ struct Pipeline::Impl {
 struct Pipeline::Banded {
     PipelineConfig cfg;                                   // the WHOLE grid, as the caller gave it
     std::vector<std::pair<int, int>> bands;               // [r0, r1), multiples of the tile height
+    detail::Grouping grouping;                            // groups' plane masks, one StateOutput per ReductionSpec
     struct Parked {
         bool any = false, on_disk = false;
-        std::vector<std::vector<float>> planes;
-        std::vector<uint32_t> touched;
+        std::vector<std::vector<float>> planes;           // [4 g + p]: the band's window of plane p of group g (empty: no such plane)
+        std::vector<uint32_t> touched;                    // tiles_x * tiles_y flags of the whole grid (only this band's rows are set)
         size_t bytes = 0;
         uint64_t stamp = 0;
     };
     std::vector<Parked> parked;
     size_t host_budget = 0, host_used = 0, spills = 0, reloads = 0;
     uint64_t clock = 0;
+    // Evicted bands live in the reference's own format and layout: one `.pcrt` file per touched reference tile and
+    // ReductionSpec (tile_RRRR_CCCC.pcrt; reduction_<i>/ for several reductions) -- what the reference's TileManager flushes
+    // on eviction (src/engine/tile_manager.cpp:76-138 -> src/io/tile_state_io.cpp:45-95) -- in a directory of the pipeline's
+    // own (under state_dir, else the temporary directory), removed with the pipeline: a spill is working state, possibly
+    // partial and older than a band's host copy, and must never be mistaken for a checkpoint.  save_state() writes one.
     std::string spill_dir;
-    bool own_spill_dir = false;
     std::unique_ptr<Grid> result;
     bool finalized = false;
     size_t collections = 0, points = 0, tiles_active = 0;
@@ -876,7 +881,7 @@ struct Pipeline::Banded {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
 
     ~Banded() {
-        if (own_spill_dir && !spill_dir.empty()) {
+        if (!spill_dir.empty()) {
             std::error_code ec;
             std::filesystem::remove_all(spill_dir, ec);
         }
@@ -884,38 +889,40 @@ struct Pipeline::Banded {
 
     // bytes of device memory one grid row costs: 4 B per cell and plane, + the finalized bands a sub-pipeline keeps
     static size_t bytes_per_row(const PipelineConfig& c) {
-        struct G { std::string ch; GlyphSpec gl; uint32_t mask; };
-        std::vector<G> gs;
-        for (const auto& r : c.reductions) {
-            int gi = -1;
-            for (size_t k = 0; k < gs.size(); ++k)
-                if (gs[k].ch == r.value_channel && same_glyph(gs[k].gl, r.glyph)) gi = (int)k;
-            if (gi < 0) { gs.push_back({r.value_channel, r.glyph, 0u}); gi = (int)gs.size() - 1; }
-            gs[gi].mask |= planes_for(r.type);
-        }
+        const detail::Grouping g = detail::group_reductions(c.reductions);
         size_t planes = 0;
-        for (const auto& g : gs)
-            for (int p = 0; p < 4; ++p) planes += (g.mask & kPlaneBits[p]) ? 1 : 0;
+        for (uint32_t m : g.masks)
+            for (int p = 0; p < 4; ++p) planes += (m & kPlaneBits[p]) ? 1 : 0;
         return (size_t)c.grid.width * 4 * (planes + c.reductions.size());
     }
 
-    std::string spill_path(size_t b) const { return spill_dir + "/band_" + std::to_string(b) + ".state"; }
+    detail::StateWindow window_of(size_t b, Parked& k) const {
+        detail::StateWindow w;
+        w.row0 = bands[b].first;
+        w.rows = bands[b].second - bands[b].first;
+        w.plane = [&k](int g, int p) -> float* {
+            auto& v = k.planes[(size_t)g * 4 + (size_t)p];
+            return v.empty() ? nullptr : v.data();
+        };
+        return w;
+    }
+
+    // a band nobody has touched yet: identity planes, no flags
+    void blank(size_t b, Parked& k) const {
+        const size_t cells = (size_t)(bands[b].second - bands[b].first) * (size_t)cfg.grid.width;
+        k.planes.assign(grouping.masks.size() * 4, {});
+        for (size_t g = 0; g < grouping.masks.size(); ++g)
+            for (int p = 0; p < 4; ++p)
+                if (grouping.masks[g] & kPlaneBits[p])
+                    k.planes[g * 4 + (size_t)p].assign(cells, p == 2 ? -3.402823466e+38f : p == 3 ? 3.402823466e+38f : 0.0f);
+        const GridConfig& g = cfg.grid;
+        k.touched.assign((size_t)((g.width + g.tile_width - 1) / g.tile_width) * (size_t)((g.height + g.tile_height - 1) / g.tile_height), 0u);
+    }
 
     Status spill(size_t b) {
         Parked& k = parked[b];
-        std::FILE* f = std::fopen(spill_path(b).c_str(), "wb");
-        if (!f) return Status::error(StatusCode::IoError, "pipeline: cannot write " + spill_path(b));
-        bool ok = true;
-        const uint64_t np = k.planes.size();
-        ok = ok && std::fwrite(&np, 8, 1, f) == 1;
-        for (const auto& pl : k.planes) {
-            const uint64_t n = pl.size();
-            ok = ok && std::fwrite(&n, 8, 1, f) == 1 && (n == 0 || std::fwrite(pl.data(), 4, n, f) == n);
-        }
-        const uint64_t nt = k.touched.size();
-        ok = ok && std::fwrite(&nt, 8, 1, f) == 1 && (nt == 0 || std::fwrite(k.touched.data(), 4, nt, f) == nt);
-        ok = (std::fclose(f) == 0) && ok;
-        if (!ok) return Status::error(StatusCode::IoError, "pipeline: short write to " + spill_path(b));
+        Status s = detail::write_state_tiles(cfg.grid, grouping.outputs, window_of(b, k), k.touched, spill_dir);
+        if (!s.ok()) return s;
         host_used -= k.bytes;
         std::vector<std::vector<float>>().swap(k.planes);
         std::vector<uint32_t>().swap(k.touched);
@@ -926,26 +933,23 @@ struct Pipeline::Banded {
 
     Status reload(size_t b) {
         Parked& k = parked[b];
-        std::FILE* f = std::fopen(spill_path(b).c_str(), "rb");
-        if (!f) return Status::error(StatusCode::IoError, "pipeline: cannot read " + spill_path(b));
-        bool ok = true;
-        uint64_t np = 0;
-        ok = ok && std::fread(&np, 8, 1, f) == 1 && np < 4096;
-        if (ok) k.planes.assign((size_t)np, {});
-        for (uint64_t i = 0; ok && i < np; ++i) {
-            uint64_t n = 0;
-            ok = std::fread(&n, 8, 1, f) == 1 && n * 4 <= k.bytes;
-            if (ok) { k.planes[i].resize((size_t)n); ok = n == 0 || std::fread(k.planes[i].data(), 4, n, f) == n; }
-        }
-        uint64_t nt = 0;
-        ok = ok && std::fread(&nt, 8, 1, f) == 1 && nt < (1u << 28);
-        if (ok) { k.touched.resize((size_t)nt); ok = nt == 0 || std::fread(k.touched.data(), 4, nt, f) == nt; }
-        std::fclose(f);
-        if (!ok) return Status::error(StatusCode::IoError, "pipeline: corrupt band state file " + spill_path(b));
+        blank(b, k);
+        size_t loaded = 0;
+        Status s = detail::read_state_tiles(cfg.grid, grouping.outputs, window_of(b, k), k.touched, spill_dir, &loaded);
+        if (!s.ok()) return s;
         k.on_disk = false;
         host_used += k.bytes;
         ++reloads;
         return Status::success();
+    }
+
+    // the host copy of a band that is unchanged since it was written to disk is dropped again (finalize, save_state)
+    void drop_host_copy(size_t b) {
+        Parked& k = parked[b];
+        host_used -= k.bytes;
+        std::vector<std::vector<float>>().swap(k.planes);
+        std::vector<uint32_t>().swap(k.touched);
+        k.on_disk = true;
     }
 
     // park band b's state (already in k.planes / k.touched) and evict the least recently used bands beyond the host budget
@@ -958,6 +962,9 @@ struct Pipeline::Banded {
         k.any = true;
         k.on_disk = false;
         k.stamp = ++clock;
+        return evict();
+    }
+    Status evict() {
         while (host_used > host_budget) {
             size_t victim = parked.size();
             for (size_t i = 0; i < parked.size(); ++i)
@@ -969,7 +976,8 @@ struct Pipeline::Banded {
         return Status::success();
     }
 
-    std::unique_ptr<Pipeline> visit(size_t b, Status* st) {
+    // was_on_disk: the band's state came from its files and those are still its current state
+    std::unique_ptr<Pipeline> visit(size_t b, Status* st, bool* was_on_disk = nullptr) {
         PipelineConfig c = cfg;
         c.shard_row_begin = bands[b].first;
         c.shard_row_end = bands[b].second;
@@ -978,11 +986,17 @@ struct Pipeline::Banded {
         c.output_path.clear();
         c.state_dir.clear();
         c.resume = false;
+        c.exec_mode = ExecutionMode::GPU;
+        c.gpu_fallback_to_cpu = false;                    // (a band is a device pipeline or an error)
+        if (was_on_disk) *was_on_disk = false;
         std::unique_ptr<Pipeline> sub = Pipeline::create(c);
         if (!sub) { *st = Status::error(StatusCode::OutOfMemory, "pipeline: out-of-core band could not be created: " + pipeline_create_error()); return nullptr; }
         Parked& k = parked[b];
         if (k.any) {
-            if (k.on_disk && !(*st = reload(b)).ok()) return nullptr;
+            if (k.on_disk) {
+                if (!(*st = reload(b)).ok()) return nullptr;
+                if (was_on_disk) *was_on_disk = true;
+            }
             if (!(*st = sub->impl_->import_window(k.planes, k.touched)).ok()) return nullptr;
             k.stamp = ++clock;
         }
@@ -1007,6 +1021,10 @@ struct Pipeline::Banded {
             last = sub->last_scatter();
             if (!parked[b].any && last.points_valid == 0) continue;        // nothing of this cloud (or any before) fell here
             Parked& k = parked[b];
+            if (last.points_valid == 0 && k.any) {                           // unchanged: the parked copy (and its files) stay current
+                if (!(s = evict()).ok()) return s;
+                continue;
+            }
             if (!(s = sub->impl_->export_window(k.planes, k.touched)).ok()) return s;
             if (!(s = account(b)).ok()) return s;
         }
@@ -1024,7 +1042,7 @@ struct Pipeline::Banded {
         std::vector<BandDesc> descs;
         for (const auto& r : cfg.reductions) {
             BandDesc d;
-            d.name = r.output_band_name.empty() ? r.value_channel + "_" + std::to_string(static_cast<int>(r.type)) : r.output_band_name;
+            d.name = detail::default_band_name(r);
             d.dtype = DataType::Float32;
             d.is_state = false;
             descs.push_back(d);
@@ -1035,7 +1053,8 @@ struct Pipeline::Banded {
         tiles_active = 0;
         for (size_t b = 0; b < bands.size(); ++b) {
             Status s = Status::success();
-            std::unique_ptr<Pipeline> sub = visit(b, &s);
+            bool from_disk = false;
+            std::unique_ptr<Pipeline> sub = visit(b, &s, &from_disk);
             if (!sub) return s;
             if (!(s = sub->finalize()).ok()) return s;
             const Grid* part = sub->result();
@@ -1044,9 +1063,55 @@ struct Pipeline::Banded {
             for (size_t o = 0; o < descs.size(); ++o)
                 std::copy_n(part->band_f32((int)o), (size_t)rows * g.width, result->band_f32((int)o) + (size_t)bands[b].first * g.width);
             for (uint32_t t : parked[b].touched) tiles_active += t ? 1 : 0;
+            // finalize changes no state: a band that was read back from its files goes back to being "on disk" at once, and
+            // the host budget holds during finalize as it does during ingest (it used to end with every band in RAM)
+            if (from_disk) drop_host_copy(b);
+            else if (!(s = evict()).ok()) return s;
         }
         finalized = true;
         if (!cfg.output_path.empty()) return write_geotiff(cfg.output_path, *result, cfg.grid, GeoTiffOptions());
+        return Status::success();
+    }
+
+    // ---- `.pcrt` checkpoints of the whole pipeline: every band's tiles under `dir` (the in-core pipeline's layout)
+    Status save_state(const std::string& dir_in) {
+        const std::string dir = dir_in.empty() ? cfg.state_dir : dir_in;
+        if (dir.empty()) return Status::error(StatusCode::InvalidArgument, "pipeline: no state directory given");
+        for (size_t b = 0; b < bands.size(); ++b) {
+            Parked& k = parked[b];
+            if (!k.any) continue;
+            bool from_disk = false;
+            Status s = Status::success();
+            if (k.on_disk) {
+                if (!(s = reload(b)).ok()) return s;
+                from_disk = true;
+            }
+            if (!(s = detail::write_state_tiles(cfg.grid, grouping.outputs, window_of(b, k), k.touched, dir)).ok()) return s;
+            if (from_disk) drop_host_copy(b);
+        }
+        return Status::success();
+    }
+
+    Status load_state(const std::string& dir_in) {
+        const std::string dir = dir_in.empty() ? cfg.state_dir : dir_in;
+        if (dir.empty()) return Status::error(StatusCode::InvalidArgument, "pipeline: no state directory given");
+        for (size_t b = 0; b < bands.size(); ++b) {
+            Parked& k = parked[b];
+            Status s = Status::success();
+            Parked fresh;
+            Parked* into = &k;
+            if (k.any) {
+                if (k.on_disk && !(s = reload(b)).ok()) return s;           // files overlay the band's current state, as in core
+            } else {
+                blank(b, fresh);
+                into = &fresh;
+            }
+            size_t loaded = 0;
+            if (!(s = detail::read_state_tiles(cfg.grid, grouping.outputs, window_of(b, *into), into->touched, dir, &loaded)).ok()) return s;
+            if (!loaded) continue;
+            if (into == &fresh) { k.planes = std::move(fresh.planes); k.touched = std::move(fresh.touched); }
+            if (!(s = account(b)).ok()) return s;
+        }
         return Status::success();
     }
 
@@ -1089,9 +1154,6 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
             const int th = g.tile_height;
             const size_t fit = budget / std::max<size_t>(per_row * (size_t)th, 1);          // whole tile rows that fit
             const int band_rows = (int)std::min<size_t>(std::max<size_t>(fit, 1) * (size_t)th, (size_t)g.height + th);
-            if (config.resume)
-                return fail_with(Status::error(StatusCode::NotImplemented,
-                    "pipeline: resume from `.pcrt` checkpoints is not supported for a grid that is processed out of core"));
             if (config.result_location == MemoryLocation::Device)
                 return fail_with(Status::error(StatusCode::InvalidArgument,
                     "pipeline: the grid's state (" + std::to_string(per_row * (size_t)g.height >> 20) + " MB) exceeds the device budget (" +
@@ -1099,6 +1161,7 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
             p->banded_ = std::make_unique<Banded>();
             Banded& bd = *p->banded_;
             bd.cfg = config;
+            bd.grouping = detail::group_reductions(config.reductions);
             for (int r0 = 0; r0 < g.height; r0 += band_rows) bd.bands.push_back({r0, std::min(r0 + band_rows, g.height)});
             bd.parked.resize(bd.bands.size());
             bd.host_budget = config.host_cache_budget;
@@ -1106,22 +1169,27 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
                 long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
                 bd.host_budget = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz / 2 : (size_t)8 << 30;
             }
-            bd.spill_dir = config.state_dir;
-            if (bd.spill_dir.empty()) {
+            {
                 std::error_code ec;
-                bd.spill_dir = (std::filesystem::temp_directory_path(ec) / ("pcr_bands_" + std::to_string((long long)getpid()) + "_" +
-                                std::to_string((unsigned long long)(uintptr_t)p.get()))).string();
-                bd.own_spill_dir = true;
+                const std::filesystem::path base = config.state_dir.empty() ? std::filesystem::temp_directory_path(ec)
+                                                                            : std::filesystem::path(config.state_dir);
+                bd.spill_dir = (base / ("pcr_spill_" + std::to_string((long long)getpid()) + "_" +
+                                        std::to_string((unsigned long long)(uintptr_t)p.get()))).string();
+                std::filesystem::create_directories(bd.spill_dir, ec);
+                if (ec) return fail_with(Status::error(StatusCode::IoError, "pipeline: cannot create " + bd.spill_dir));
             }
-            std::error_code ec;
-            std::filesystem::create_directories(bd.spill_dir, ec);
-            if (ec) return fail_with(Status::error(StatusCode::IoError, "pipeline: cannot create " + bd.spill_dir));
             // the first band is created once here, so that an impossible configuration fails at create like an in-core one
             Status s = Status::success();
             std::unique_ptr<Pipeline> probe = bd.visit(0, &s);
             if (!probe) return fail_with(s);
             std::fprintf(stderr, "Info: grid state %zu MB exceeds the device budget %zu MB - out of core in %zu bands of %d rows\n",
                          per_row * (size_t)g.height >> 20, budget >> 20, bd.bands.size(), band_rows);
+            probe.reset();
+            if (config.resume && !config.state_dir.empty()) {
+                // the tiles under state_dir are taken band by band (and, beyond the host budget, go back there: same files)
+                s = bd.load_state(config.state_dir);
+                if (!s.ok()) return fail_with(s);
+            }
             g_create_error.clear();
             return p;
         }
@@ -1153,6 +1221,7 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
 }
 
 const char* Pipeline::engine() const { return host_ ? "host" : "hip"; }
+std::string Pipeline::spill_dir() const { return banded_ ? banded_->spill_dir : std::string(); }
 
 Status Pipeline::validate() const {
     const PipelineConfig& c = host_ ? host_->cfg : banded_ ? banded_->cfg : impl_->cfg;
@@ -1288,12 +1357,12 @@ Status Pipeline::merge_touched(const void* d_union) {
 
 Status Pipeline::save_state(const std::string& dir) {
     if (host_) return host_->save_state(dir);
-    if (banded_) return Status::error(StatusCode::NotImplemented, "pipeline: `.pcrt` checkpoints of an out-of-core pipeline are not supported");
+    if (banded_) return banded_->save_state(dir);
     return impl_->save_state(dir);
 }
 Status Pipeline::load_state(const std::string& dir) {
     if (host_) return host_->load_state(dir);
-    if (banded_) return Status::error(StatusCode::NotImplemented, "pipeline: `.pcrt` checkpoints of an out-of-core pipeline are not supported");
+    if (banded_) return banded_->load_state(dir);
     return impl_->load_state(dir);
 }
 

@@ -28,7 +28,7 @@ TileRect tile_rect(const GridConfig& g, const StateWindow& w, int tx, int ty) {
 }  // namespace
 
 Status write_state_tiles(const GridConfig& g, const std::vector<StateOutput>& outputs, const StateWindow& w,
-                         const std::vector<uint32_t>& touched, const std::string& dir) {
+                         const std::vector<uint32_t>& touched, const std::string& dir, std::vector<std::string>* written) {
     const int tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
     const int tiles_y = (g.height + g.tile_height - 1) / g.tile_height;
     std::error_code ec;
@@ -54,8 +54,10 @@ Status write_state_tiles(const GridConfig& g, const std::vector<StateOutput>& ou
                 TileIndex ti;
                 ti.row = ty;
                 ti.col = tx;
-                Status s = write_tile_state(tile_state_filename(rdir, ti), ti, t.nc, t.nr, k, outputs[r].type, buf.data());
+                const std::string path = tile_state_filename(rdir, ti);
+                Status s = write_tile_state(path, ti, t.nc, t.nr, k, outputs[r].type, buf.data());
                 if (!s.ok()) return s;
+                if (written) written->push_back(path);
             }
     }
     return Status::success();

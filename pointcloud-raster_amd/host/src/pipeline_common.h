@@ -77,6 +77,25 @@ struct StateOutput {
     ReductionType type;
 };
 
+// ReductionSpecs -> accumulation groups (same value channel through the same glyph = one pass, one set of planes).
+struct Grouping {
+    std::vector<uint32_t> masks;             // per group: planes it keeps
+    std::vector<StateOutput> outputs;        // per ReductionSpec
+};
+inline Grouping group_reductions(const std::vector<ReductionSpec>& reductions) {
+    Grouping out;
+    std::vector<const ReductionSpec*> first;
+    for (const auto& r : reductions) {
+        int gi = -1;
+        for (size_t k = 0; k < first.size(); ++k)
+            if (first[k]->value_channel == r.value_channel && same_glyph(first[k]->glyph, r.glyph)) gi = (int)k;
+        if (gi < 0) { first.push_back(&r); out.masks.push_back(0u); gi = (int)first.size() - 1; }
+        out.masks[(size_t)gi] |= planes_for(r.type);
+        out.outputs.push_back({gi, r.type});
+    }
+    return out;
+}
+
 // Host copies of state planes over the row WINDOW [row0, row0 + rows) of the grid (whole tile rows for everything below):
 // plane(group, p) -> rows x width floats, or null when the group has no plane p.
 struct StateWindow {
@@ -89,7 +108,7 @@ std::string reduction_state_dir(const std::string& dir, size_t r, size_t n_outpu
 /// One `.pcrt` file per touched reference tile inside the window and per output (src/io/tile_state_io.cpp:45-95;
 /// file name src/io/tile_state_io.cpp:197-211).  touched: tiles_x * tiles_y flags of the whole grid.
 Status write_state_tiles(const GridConfig& g, const std::vector<StateOutput>& outputs, const StateWindow& w,
-                         const std::vector<uint32_t>& touched, const std::string& dir);
+                         const std::vector<uint32_t>& touched, const std::string& dir, std::vector<std::string>* written = nullptr);
 /// The reverse: every matching file inside the window is copied into the planes and its tile marked touched; files that do
 /// not describe their tile of their reduction are ignored like the reference's tile manager ignores them
 /// (src/engine/tile_manager.cpp:272-320).  *loaded = files taken.
