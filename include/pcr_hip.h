@@ -32,7 +32,7 @@ extern "C" {
 
 #define PCR_HIP_ABI_VERSION 5   /* 3 (round 4): + comm_halo_plan / comm_agree_max_i32 / signed_max_f32_masked / copy_kernel; planes_fresh takes 0, 1, 2;
                                  * 4: + engine_finalize_with_scatter / engine_finalize_taken / finalize_group_unless / touched_union;
-                                 * 5 (round 5): + comm_alltoall_counts / comm_alltoallv / comm_gatherv / comm_xfer_plan; halo_reduce resets the sent apron rows */
+                                 * 5 (round 5): + comm_alltoall_counts / comm_alltoallv / comm_gatherv / comm_xfer_plan / touched_union_owned; halo_reduce resets the sent apron rows */
 
 typedef enum pcr_hip_status {
     PCR_HIP_OK = 0,
@@ -188,6 +188,12 @@ int pcr_hip_finalize_group_unless(const pcr_hip_grid* g, const pcr_hip_planes* p
  * (pcr_hip_finalize_group_unless).  Unchanged flags leave them alone -- the usual case on dense clouds. */
 int pcr_hip_touched_union(uint32_t* d_local, const uint32_t* d_union, int32_t n, uint32_t* d_bands_done, int32_t n_words,
                           pcr_hip_stream s);
+/* The same over a tiles_x x tiles_y flag grid for a device that owns rows of tile rows [own_tile_row0, own_tile_row1) only: a
+ * flag that changes OUTSIDE that range is merged but leaves d_bands_done alone -- none of this device's bands depends on it
+ * (non-tile-aligned row blocks: every other rank contributes tiles this one owns no row of). */
+int pcr_hip_touched_union_owned(uint32_t* d_local, const uint32_t* d_union, int32_t tiles_x, int32_t tiles_y,
+                                int32_t own_tile_row0, int32_t own_tile_row1, uint32_t* d_bands_done, int32_t n_words,
+                                pcr_hip_stream s);
 
 /* ---- scatter engine.  replaces: TileRouter::assign + sort + extract_batches
  *      (include/pcr/engine/tile_router_kernels.h:15-52, src/engine/tile_router.cpp:51-366),

@@ -46,6 +46,14 @@ __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) &
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
+// The bin geometry in vector registers too (see vector_resident in common.hpp): the kernels below route with it per point.
+__device__ __forceinline__ BinGeom vector_resident(const BinGeom& u) {
+    BinGeom b = u;
+    b.tile_w = pcrhip::vector_resident(u.tile_w); b.tile_h = pcrhip::vector_resident(u.tile_h);
+    b.bins_x = pcrhip::vector_resident(u.bins_x); b.row0 = pcrhip::vector_resident(u.row0);
+    return b;
+}
+
 // ---- classification shared by both passes ------------------------------------------------------------------
 // 0: not this band's point; 1: binned (bin, lcell valid); 2: valid but not representable by geometry -> list
 struct Routed16 {
@@ -79,9 +87,11 @@ __device__ __forceinline__ Routed16 classify(const GridDev& g, const BinGeom& b,
 // ---- pass A: counts per (virtual XCD, tile); x, y only ---------------------------------------------------------
 template <bool CENTRE>
 __global__ void __launch_bounds__(kCountThreads)
-k_b16_count(GridDev g, BinGeom b, int cb, const double* __restrict__ x, const double* __restrict__ y, uint64_t n,
+k_b16_count(GridDev g_uniform, BinGeom b_uniform, int cb, const double* __restrict__ x, const double* __restrict__ y, uint64_t n,
             unsigned* __restrict__ cnt, unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count,
             uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
+    const GridDev g = pcrhip::vector_resident<PCR_VRES_B16_COUNT>(g_uniform);      // (common.hpp: the scalar registers do not hold all of it)
+    const BinGeom b = PCR_VRES_B16_COUNT >= 2 ? vector_resident(b_uniform) : b_uniform;
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
@@ -224,9 +234,12 @@ k_b16_scan(int nbins, unsigned item_records, const unsigned* __restrict__ cnt, u
 // ---- pass B: records straight from registers -------------------------------------------------------------------
 template <class Maker>
 __global__ void __launch_bounds__(kScatThreads, 4)     // <= 128 VGPRs: two 512-thread workgroups per CU
-k_b16_scatter(GridDev g, BinGeom b, Maker mk, const double* __restrict__ x, const double* __restrict__ y,
+k_b16_scatter(GridDev g_uniform, BinGeom b_uniform, Maker mk, const double* __restrict__ x, const double* __restrict__ y,
               const float* __restrict__ v, uint64_t n, unsigned* __restrict__ cursor, uint4* __restrict__ records,
               unsigned* __restrict__ fb_list, unsigned* __restrict__ fb_count) {
+    // (common.hpp: the scalar registers do not hold all of it -- for the Makers that have the vector registers to spare)
+    const GridDev g = Maker::kVectorGeometry ? pcrhip::vector_resident<PCR_VRES_B16_SCATTER>(g_uniform) : g_uniform;
+    const BinGeom b = Maker::kVectorGeometry && PCR_VRES_B16_SCATTER >= 2 ? vector_resident(b_uniform) : b_uniform;
     extern __shared__ unsigned lds_hist[];                  // [nbins]: rank counters, then the run's global start
     // Makers with a rare long way (kFixup): the points that need it are LISTED in LDS by the unrolled main loop -- which then
     // holds the short way only -- and handled afterwards by as many lanes as there are such points.  (A rare per-lane branch

@@ -161,6 +161,54 @@ __device__ __forceinline__ uint2 stream_load(const uint2* p) {
     return make_uint2(t.x, t.y);
 }
 
+// A routing kernel's wave-uniform constants all want scalar registers -- eight doubles of grid geometry, the tile and bin
+// geometry with the float reciprocals fast_div derives from them, five or six array bases, the loop state -- and the 102 a
+// wave has do not hold them: round 4's count passes spilled 21-47 of them to VGPR lanes and read them back inside the point
+// loop.  The routing arithmetic is vector work anyway (an f64 VALU instruction takes one scalar operand at most), so the
+// geometry is moved into VECTOR registers once, behind an asm the compiler cannot see through (it would move the values back).
+// How far each family of routing kernels goes: 0 = everything scalar (round 4), 1 = the eight doubles, 2 = + the integer
+// geometry.  A/B'd in one call (profiles/r05_sgpr_spills.md): level 1 ends the spills of the headline's count pass and is
+// neutral everywhere; level 2 ends nearly all of them and COSTS -- the vector registers it takes push k_b16_count, the
+// Line scatter pass and the multi-tile k_bin_count over an occupancy step (+0.05 to +0.17 ms) -- so level 1 it is: what is
+// left spilled is read back with one v_readlane per use and shows in no timing.
+#ifndef PCR_VRES_POINT
+#define PCR_VRES_POINT 1
+#endif
+#ifndef PCR_VRES_B16_COUNT
+#define PCR_VRES_B16_COUNT 1
+#endif
+#ifndef PCR_VRES_B16_SCATTER
+#define PCR_VRES_B16_SCATTER 1
+#endif
+__device__ __forceinline__ double vector_resident(double uniform) {
+    double v;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(v) : "s"(uniform));
+    return v;
+}
+__device__ __forceinline__ int vector_resident(int uniform) {
+    int v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+    return v;
+}
+// ints: also the tile geometry (the multi-tile variants, whose touched-tile bookkeeping needs still more scalars)
+template <int LEVEL>
+__device__ __forceinline__ GridDev vector_resident(const GridDev& u) {
+    constexpr bool INTS = LEVEL >= 2;
+    GridDev g = u;
+    if (LEVEL <= 0) return g;
+    g.min_x = vector_resident(u.min_x); g.max_x = vector_resident(u.max_x);
+    g.min_y = vector_resident(u.min_y); g.max_y = vector_resident(u.max_y);
+    g.csx = vector_resident(u.csx); g.csy = vector_resident(u.csy);
+    g.inv_csx = vector_resident(u.inv_csx); g.inv_csy = vector_resident(u.inv_csy);
+    if (INTS) {
+        g.own_r0 = vector_resident(u.own_r0); g.own_r1 = vector_resident(u.own_r1);
+        g.st_r0 = vector_resident(u.st_r0);
+        g.W = vector_resident(u.W); g.H = vector_resident(u.H);
+        g.tw = vector_resident(u.tw); g.th = vector_resident(u.th); g.tiles_x = vector_resident(u.tiles_x);
+    }
+    return g;
+}
+
 // Point filter (FilterSpec): applied where a kernel decides a point's validity.
 __device__ __forceinline__ bool point_kept(const GridDev& g, uint64_t i) { return g.mask == nullptr || g.mask[i] != 0; }
 

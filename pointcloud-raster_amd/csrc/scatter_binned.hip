@@ -55,20 +55,24 @@ constexpr int kCountThreads = 512;
 // Blocks [0, full_blocks) take b.chunk points each, the blocks after them 4096 points each (the ragged end): the SAME
 // block -> points mapping as k_bin_scatter's, because with nvx = 8 the counts are kept per virtual XCD (blockIdx % 8) and a
 // point must be counted under the virtual XCD that will store its record (see bin_points).  nvx = 1: one count per bin.
-template <bool MULTI>
+// ONE_TILE: the grid is one reference tile (C2, C4: the whole touched-tile bookkeeping -- its LDS flags, two more divisors and
+// their reciprocals -- is compiled out; the workgroup's first thread flags the tile).
+template <bool MULTI, bool ONE_TILE>
 __global__ void __launch_bounds__(kCountThreads)
-k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, const double* __restrict__ x, const double* __restrict__ y,
+k_bin_count(GridDev g_uniform, BinGeom b, unsigned full_blocks, int split, int nvx, const double* __restrict__ x, const double* __restrict__ y,
             uint64_t n, unsigned* __restrict__ keys, unsigned* __restrict__ bin_count,
             uint32_t* __restrict__ touched, unsigned long long* __restrict__ counters) {
+    // (common.hpp: the scalar registers do not hold all of it; the one-tile variant needs the doubles only)
+    const GridDev g = vector_resident<(ONE_TILE ? (PCR_VRES_POINT > 0 ? 1 : 0) : PCR_VRES_POINT)>(g_uniform);
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < b.nbins; i += kCountThreads) lds_hist[i] = 0;
     __shared__ unsigned any_valid;
-    __shared__ unsigned lds_touch[kTouchLdsTiles];
+    __shared__ unsigned lds_touch[ONE_TILE ? 1 : kTouchLdsTiles];
     TouchLds tl;
-    tl.begin(g, lds_touch, kCountThreads);
+    if (!ONE_TILE) tl.begin(g, lds_touch, kCountThreads);
     if (threadIdx.x == 0) any_valid = 0;
     __syncthreads();
-    const bool one_tile = g.tiles_x * g.tiles_y == 1;
+    constexpr bool one_tile = ONE_TILE;
     // Block -> points.  MULTI = false: a scatter block's points are counted by `split` workgroups (all under the scatter
     // block's virtual XCD) -- the count pass wants more, shorter workgroups than the scatter pass has chunks.  MULTI = true
     // (`split` then holds cb): ONE workgroup counts cb scatter blocks of one virtual XCD (blocks vx, vx + 8, ...) -- with
@@ -148,11 +152,17 @@ k_bin_count(GridDev g, BinGeom b, unsigned full_blocks, int split, int nvx, cons
         unsigned c = lds_hist[i];
         if (c) atomicAdd(&mine[i], c);
     }
-    tl.flush(g, touched, kCountThreads);
+    if (!ONE_TILE) tl.flush(g, touched, kCountThreads);
     if (threadIdx.x == 0 && any_valid) {
         atomicAdd(counters, (unsigned long long)any_valid);
         if (one_tile) touched[0] = 1u;
     }
+}
+
+template <bool MULTI, class... Args>
+void launch_bin_count(bool one_tile, dim3 grid, size_t lds, hipStream_t stream, Args... args) {
+    if (one_tile) hipLaunchKernelGGL((k_bin_count<MULTI, true>), grid, dim3(kCountThreads), lds, stream, args...);
+    else hipLaunchKernelGGL((k_bin_count<MULTI, false>), grid, dim3(kCountThreads), lds, stream, args...);
 }
 
 // Points per workgroup of the count pass.  Every block flushes its LDS histogram with up to nbins global atomics, so many
@@ -832,13 +842,13 @@ int bin_points(pcr_hip_engine* e, const GridDev& gd, const BinGeom& b, const dou
         const unsigned tail_blocks = (unsigned)((n - done + 4095) / 4096);
         if (cb > 1) {
             const unsigned cblocks = (unsigned)nvx * (((unsigned)(full_blocks + nvx - 1) / nvx + cb - 1) / cb) + tail_blocks;
-            hipLaunchKernelGGL(k_bin_count<true>, dim3(cblocks), dim3(kCountThreads), (size_t)b.nbins * 4, e->stream,
-                               gd, bc, (unsigned)full_blocks, cb, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+            launch_bin_count<true>(gd.tiles_x * gd.tiles_y == 1, dim3(cblocks), (size_t)b.nbins * 4, e->stream,
+                                   gd, bc, (unsigned)full_blocks, cb, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
         } else {
             const int split = count_split(bc.chunk, b.nbins);
-            hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)full_blocks * (unsigned)split + tail_blocks), dim3(kCountThreads),
-                               (size_t)b.nbins * 4, e->stream,
-                               gd, bc, (unsigned)full_blocks, split, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
+            launch_bin_count<false>(gd.tiles_x * gd.tiles_y == 1, dim3((unsigned)full_blocks * (unsigned)split + tail_blocks),
+                                    (size_t)b.nbins * 4, e->stream,
+                                    gd, bc, (unsigned)full_blocks, split, nvx, x, y, n, d_keys, d_count, e->d_touched, e->d_counters);
         }
     }
     {
@@ -908,13 +918,13 @@ int bin_points_two_level(pcr_hip_engine* e, const BinGeom& tiles, const double* 
         const unsigned tail_blocks = blocks - (unsigned)full_blocks;
         if (cb > 1) {
             const unsigned cblocks = (unsigned)nvx * (((unsigned)(full_blocks + nvx - 1) / nvx + cb - 1) / cb) + tail_blocks;
-            hipLaunchKernelGGL(k_bin_count<true>, dim3(cblocks), dim3(kCountThreads), (size_t)l1.nbins * 4, e->stream,
-                               e->gd, l1, (unsigned)full_blocks, cb, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+            launch_bin_count<true>(e->gd.tiles_x * e->gd.tiles_y == 1, dim3(cblocks), (size_t)l1.nbins * 4, e->stream,
+                                   e->gd, l1, (unsigned)full_blocks, cb, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
         } else {
             const int split = count_split(l1.chunk, l1.nbins);
-            hipLaunchKernelGGL(k_bin_count<false>, dim3((unsigned)full_blocks * (unsigned)split + tail_blocks), dim3(kCountThreads),
-                               (size_t)l1.nbins * 4, e->stream,
-                               e->gd, l1, (unsigned)full_blocks, split, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
+            launch_bin_count<false>(e->gd.tiles_x * e->gd.tiles_y == 1, dim3((unsigned)full_blocks * (unsigned)split + tail_blocks),
+                                    (size_t)l1.nbins * 4, e->stream,
+                                    e->gd, l1, (unsigned)full_blocks, split, nvx, x, y, n, U(o_keys), U(o_count1), e->d_touched, e->d_counters);
         }
     }
     {

@@ -175,6 +175,7 @@ k_tile_gauss(GridDev g, GlyphDev gl, GlyphTile t, PlanesDev pl, const uint2* __r
 // centre cell's reference tile, Q4) follows from the centre cell.  A segment whose end points do not fit an int16
 // offset (a garbage half_length: |offset| > 32000 cells) goes to the list and is walked by the direct form.
 struct LineRecMaker {
+    static constexpr bool kVectorGeometry = false;     // k_b16_scatter: grid and bin geometry in vector registers (bin16.hpp)
     static constexpr bool kCentre = false;
     static constexpr bool kOwnsX = false;
     static constexpr bool kFixup = false;
@@ -284,6 +285,7 @@ k_tile_line16(GridDev g, GlyphTile t, PlanesDev pl, const uint4* __restrict__ re
 // Used when the LDS apron covers the glyph's reach (default half length: every kept cell lies inside the window) and the
 // window's pitch fits an int8 step; the other cases keep the end-point records above.
 struct LineStateMaker {
+    static constexpr bool kVectorGeometry = true;     // k_b16_scatter: grid and bin geometry in vector registers (bin16.hpp)
     static constexpr bool kCentre = false;
     static constexpr bool kOwnsX = true;
     static constexpr bool kFixup = true;

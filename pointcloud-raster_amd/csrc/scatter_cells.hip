@@ -46,6 +46,7 @@ namespace {
 // Gaussian cell records {local cell, value, sub-cell x, sub-cell y}: sub = (float)(fc - floor(fc)), the reference's
 // f32 sub-cell offset (glyph_kernels.cu:116-117).
 struct GaussCellMaker {
+    static constexpr bool kVectorGeometry = false;     // k_b16_scatter: grid and bin geometry in vector registers (bin16.hpp)
     static constexpr bool kCentre = true;
     static constexpr bool kOwnsX = false;
     static constexpr bool kFixup = false;

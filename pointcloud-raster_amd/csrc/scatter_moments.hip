@@ -56,6 +56,7 @@ __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) &
 typedef float pcr_f2 __attribute__((ext_vector_type(2)));
 
 struct MomentMaker {
+    static constexpr bool kVectorGeometry = false;     // k_b16_scatter: grid and bin geometry in vector registers (bin16.hpp)
     static constexpr bool kCentre = true;
     static constexpr bool kOwnsX = false;
     static constexpr bool kFixup = false;

@@ -323,24 +323,44 @@ int pcr_hip_filter_mask(const pcr_hip_predicate* preds, int n_pred, uint64_t n, 
 }
 
 namespace {
+// [own_lo, own_hi): the flags (row-major over the tile grid) whose tiles hold rows this device OWNS.  A flag another rank set
+// for a tile this device owns no row of changes none of this device's bands: only a change inside the range drops them.
 __global__ void __launch_bounds__(256)
-k_touched_union(uint32_t* __restrict__ local, const uint32_t* __restrict__ other, int n, uint32_t* __restrict__ done, int n_words) {
+k_touched_union(uint32_t* __restrict__ local, const uint32_t* __restrict__ other, int n, int own_lo, int own_hi,
+                uint32_t* __restrict__ done, int n_words) {
     __shared__ unsigned changed;
     if (threadIdx.x == 0) changed = 0u;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256)
-        if (other[i] != 0u && local[i] == 0u) { local[i] = 1u; changed = 1u; }      // (every writer stores 1)
+        if (other[i] != 0u && local[i] == 0u) {
+            local[i] = 1u;                                                         // (every writer stores 1)
+            if (i >= own_lo && i < own_hi) changed = 1u;
+        }
     __syncthreads();
     if (changed && done)
         for (int w = threadIdx.x; w < n_words; w += 256) done[w] = 0u;
 }
 }  // namespace
 
+int pcr_hip_touched_union_owned(uint32_t* d_local, const uint32_t* d_union, int32_t tiles_x, int32_t tiles_y,
+                                int32_t own_tile_row0, int32_t own_tile_row1, uint32_t* d_bands_done, int32_t n_words,
+                                pcr_hip_stream s) {
+    PCR_REQUIRE(d_local && d_union && tiles_x >= 0 && tiles_y >= 0 && n_words >= 0, "touched_union: bad argument");
+    PCR_REQUIRE(own_tile_row0 >= 0 && own_tile_row0 <= own_tile_row1 && own_tile_row1 <= tiles_y,
+                "touched_union: owned tile rows outside the tile grid");
+    if ((int64_t)tiles_x * tiles_y == 0) return PCR_HIP_OK;
+    PCR_REQUIRE((int64_t)tiles_x * tiles_y < (1ll << 31), "touched_union: tile grid too large");
+    hipLaunchKernelGGL(k_touched_union, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d_local, d_union, tiles_x * tiles_y,
+                       own_tile_row0 * tiles_x, own_tile_row1 * tiles_x, d_bands_done, (int)n_words);
+    PCR_HIP_TRY(hipGetLastError());
+    return PCR_HIP_OK;
+}
+
 int pcr_hip_touched_union(uint32_t* d_local, const uint32_t* d_union, int32_t n, uint32_t* d_bands_done, int32_t n_words,
                           pcr_hip_stream s) {
     PCR_REQUIRE(d_local && d_union && n >= 0 && n_words >= 0, "touched_union: bad argument");
     if (n == 0) return PCR_HIP_OK;
-    hipLaunchKernelGGL(k_touched_union, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d_local, d_union, (int)n,
+    hipLaunchKernelGGL(k_touched_union, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d_local, d_union, (int)n, 0, (int)n,
                        d_bands_done, (int)n_words);
     PCR_HIP_TRY(hipGetLastError());
     return PCR_HIP_OK;

@@ -234,6 +234,9 @@ struct Pipeline::Impl {
             for (const auto& gr : groups) halo = std::max(halo, reach_rows(gr.glyph));
             halo = std::max(halo, cfg.shard_halo_rows);
             halo = std::min(halo, g.height);
+            // -2 (the out-of-core bands): the block is made of whole reference-tile rows, footprints are clipped to the tile
+            // of their centre cell (Q4), nothing can land outside the block -- no apron rows at all
+            if (cfg.shard_halo_rows == -2 && r0 % g.tile_height == 0 && (r1 % g.tile_height == 0 || r1 == g.height)) halo = 0;
         }
         hg.min_x = g.bounds.min_x; hg.min_y = g.bounds.min_y; hg.max_x = g.bounds.max_x; hg.max_y = g.bounds.max_y;
         hg.cell_size_x = g.cell_size_x; hg.cell_size_y = g.cell_size_y;
@@ -983,6 +986,7 @@ struct Pipeline::Banded {
         c.shard_row_end = bands[b].second;
         c.result_location = MemoryLocation::Host;
         c.finalize_with_first_ingest = false;             // (a band's visit ends with its state parked, never with finalize)
+        c.shard_halo_rows = -2;                           // whole tile rows: the band's state window is the band
         c.output_path.clear();
         c.state_dir.clear();
         c.resume = false;
@@ -1306,7 +1310,12 @@ std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
     if (banded_ || host_) return out;
     {
         Impl::DeviceScope dev(impl_->cfg.cuda_device_id);
+        bool filled = false;
+        for (const auto& g : impl_->groups) filled = filled || !g.defined;
         (void)impl_->define_all_planes();               // the caller reads (and may write) them: identity where nothing was ingested
+        // The fills run on the pipeline's stream and the caller may read on any other (torch's current stream, a host copy):
+        // they are complete when the pointers leave.  Planes that were already defined cost no synchronisation.
+        if (filled) (void)pcr_hip_stream_synchronize(impl_->stream);
     }
     for (auto& g : impl_->groups) g.fresh = false;      // mutable pointers leave the pipeline: assume the planes get written
     impl_->state_shared = true;
@@ -1350,9 +1359,13 @@ Status Pipeline::merge_touched(const void* d_union) {
     Status s = detail::hip_status(pcr_hip_engine_tile_touched(impl_->engine, &d, &tx, &ty));
     if (!s.ok()) return s;
     // (the stored bands' device words decide: the host keeps offering them to finalize, whose kernel runs when they are 0)
-    return detail::hip_status(pcr_hip_touched_union(d, static_cast<const uint32_t*>(d_union), tx * ty,
-                                                    static_cast<uint32_t*>(impl_->d_bands_done.data()),
-                                                    (int32_t)impl_->groups.size(), impl_->stream));
+    // only a flag of a tile this device owns rows of can change its bands (the union used to drop the stored
+    // bands whenever ANY tile of the grid changed, i.e. always, on shards that do not share every tile)
+    const int th = impl_->cfg.grid.tile_height;
+    const int t0 = impl_->hg.own_row0 / th, t1 = std::min(ty, (impl_->hg.own_row1 + th - 1) / th);
+    return detail::hip_status(pcr_hip_touched_union_owned(d, static_cast<const uint32_t*>(d_union), tx, ty, std::min(t0, t1), t1,
+                                                          static_cast<uint32_t*>(impl_->d_bands_done.data()),
+                                                          (int32_t)impl_->groups.size(), impl_->stream));
 }
 
 Status Pipeline::save_state(const std::string& dir) {

@@ -132,6 +132,7 @@ SYMBOLS = {
     "pcr_hip_finalize": [C.c_int, C.POINTER(Grid), C.POINTER(Planes), _VP, _VP, _VP],
     "pcr_hip_finalize_group": [C.POINTER(Grid), C.POINTER(Planes), _VP, C.c_int, C.POINTER(C.c_int), C.POINTER(_VP), _VP],
     "pcr_hip_touched_union": [_VP, _VP, C.c_int32, _VP, C.c_int32, _VP],
+    "pcr_hip_touched_union_owned": [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, C.c_int32, _VP],
     "pcr_hip_finalize_group_unless": [C.POINTER(Grid), C.POINTER(Planes), _VP, C.c_int, C.POINTER(C.c_int), C.POINTER(_VP), _VP, _VP],
     "pcr_hip_engine_create": [C.POINTER(_VP), C.POINTER(Grid), _SZ, _VP],
     "pcr_hip_engine_destroy": [_VP],
