@@ -200,7 +200,6 @@ int pcr_hip_engine_create(pcr_hip_engine** out, const pcr_hip_grid* g, size_t sc
         if (v >= 1 && v < kMaxBins) e->max_bins = v;
     }
     if (const char* dbg = std::getenv("PCR_HIP_DEBUG_TWO_LEVEL")) e->two_level = std::atoi(dbg) != 0;
-    if (const char* t = std::getenv("PCR_HIP_TUNE_CONV")) e->tune_conv = std::atoi(t);
     hipError_t err = hipGetDevice(&e->device);
     hipDeviceProp_t prop;
     if (err == hipSuccess) err = hipGetDeviceProperties(&prop, e->device);

@@ -21,8 +21,6 @@ struct pcr_hip_engine {
     int max_bins = 0;                          // LDS tiles per binning pass (kMaxBins; PCR_HIP_DEBUG_MAX_BINS lowers it
                                                // so that tests reach the large-grid paths on small grids)
     int stats_scatter_chunk = 0;               // points per k_bin_scatter workgroup of the last binned scatter
-    int tune_conv = 0;                         // PCR_HIP_TUNE_CONV=1 / 2: force the vector-ALU / matrix-core column pass of the moment
-                                               // path (tests reach both kernels on small shapes)
     bool two_level = true;                     // PCR_HIP_DEBUG_TWO_LEVEL=0 forces the row-band sweep instead
     pcr_hip_scatter_stats stats{};
     int planes_fresh = 0;                      // pcr_hip_engine_planes_fresh, for the NEXT scatter: 0 its planes hold earlier

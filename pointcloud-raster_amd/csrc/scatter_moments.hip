@@ -1000,8 +1000,8 @@ int moments_gauss(pcr_hip_engine* e, const GlyphDev& gl, uint32_t mask, const Pl
             {
                 ScopedKernelTimer t(e, "k_conv_col");
                 // matrix-core sweep from r = 24 (15 % faster at r = 48, 7 % slower at r = 12 where the pass is HBM-bound
-                // either way); PCR_HIP_TUNE_CONV = 1 / 2 force the vector-ALU / the MFMA sweep (experiments)
-                if (e->tune_conv == 2 || (e->tune_conv != 1 && p.r >= 24)) {
+                // either way)
+                if (p.r >= 24) {
                     const int ni = (col_rows_mfma + 15) / 16;         // 16-row staging rounds (four waves)
                     const int ni8 = (col_rows_mfma8 + 31) / 32;       // 32-row staging rounds (eight waves)
                     const bool vec = g.W % 4 == 0 && cells % 4 == 0 && (reinterpret_cast<uintptr_t>(mom) & 15) == 0;

@@ -178,6 +178,8 @@ public:
     std::string spill_dir() const;
     /// "hip" (the MI355X engine) or "host" (ExecutionMode::CPU, or a fallback the reference would have taken too).
     const char* engine() const;
+    /// OpenMP threads of the host engine (cpu_threads, or every CPU the process may use: affinity and cgroup quota); 0 on "hip".
+    int host_threads() const;
 
 private:
     Pipeline() = default;

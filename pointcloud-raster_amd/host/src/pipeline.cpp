@@ -1225,6 +1225,7 @@ std::unique_ptr<Pipeline> Pipeline::create(const PipelineConfig& config) {
 }
 
 const char* Pipeline::engine() const { return host_ ? "host" : "hip"; }
+int Pipeline::host_threads() const { return host_ && host_->engine ? host_->engine->threads() : 0; }
 std::string Pipeline::spill_dir() const { return banded_ ? banded_->spill_dir : std::string(); }
 
 Status Pipeline::validate() const {

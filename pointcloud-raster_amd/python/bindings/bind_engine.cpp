@@ -196,6 +196,7 @@ void bind_engine(py::module_& m) {
         })
         .def("engine", [](const Pipeline& p) { return std::string(p.engine()); },
              "'hip' (the MI355X engine) or 'host' (ExecutionMode.CPU, or a fallback the reference would have taken too)")
+        .def("host_threads", &Pipeline::host_threads, "OpenMP threads of the host engine; 0 on the HIP engine")
         .def("spill_dir", &Pipeline::spill_dir, "Out of core: the directory of evicted bands (`.pcrt` tiles, reference layout); '' otherwise")
         .def("out_of_core", &Pipeline::out_of_core,
              "True when the grid's state exceeds gpu_memory_budget and the pipeline sweeps it in row bands of whole reference-tile rows");

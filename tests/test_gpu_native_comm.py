@@ -173,6 +173,55 @@ def test_native_sharded_pipeline_world_one_matches_oracle(tmp_path):
     assert "sharded world-one ok" in _run_child(_SHARDED_WORLD_ONE, str(tmp_path))
 
 
+_PY_NATIVE_ROUTE = r"""
+import ctypes as C, os, sys
+import numpy as np
+import torch                                   # before pcr: one shared HIP runtime
+HERE = sys.argv[1]
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
+import pcr
+from pcr import _cabi as A
+from pcr.distributed import partition_cloud, _alltoallv_native
+L = A.lib()
+ident = (C.c_uint8 * 128)()
+A.check(L.pcr_hip_comm_unique_id(ident))
+comm = C.c_void_p()
+A.check(L.pcr_hip_comm_create(C.byref(comm), ident, 0, 1, 0))
+G, n = 300, 50000
+rng = np.random.default_rng(12)
+x, y = rng.uniform(-20, G + 20, n), rng.uniform(-20, G + 20, n)      # some points outside the grid: dropped at the partition
+v = rng.uniform(0, 1, n).astype(np.float32)
+cloud = pcr.PointCloud.create(n)
+cloud.set_x_array(x)
+cloud.set_y_array(y)
+cloud.add_channel("value", pcr.DataType.Float32)
+cloud.set_channel_array_f32("value", v)
+dev = cloud.to_device()
+gc = pcr.GridConfig()
+gc.bounds = pcr.BBox(0.0, 0.0, float(G), float(G))
+gc.compute_dimensions()
+counts, grouped = partition_cloud(dev, gc, [(0, G)])
+inside = (x >= 0) & (x <= G) & (y >= 0) & (y <= G)
+assert counts == [int(inside.sum())]
+mine = _alltoallv_native(comm, dev, counts, grouped, 1, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert mine.count() == counts[0] and mine.location() == pcr.MemoryLocation.Device
+host = mine.to_host()
+got = np.stack([np.array(host.x_array()), np.array(host.y_array()), np.array(host.channel_array_f32("value")).astype(np.float64)])
+want = np.stack([x[inside], y[inside], v[inside].astype(np.float64)])
+assert np.array_equal(got[:, np.lexsort(got)], want[:, np.lexsort(want)])          # the same points, whatever their order
+A.check(L.pcr_hip_comm_destroy(comm))
+print("python native route ok")
+"""
+
+
+def test_python_route_through_the_native_alltoallv_world_one():
+    """route_cloud(comm=...) -- the Python side of pcr_hip_comm_alltoall_counts / _alltoallv -- at world 1: the partition's groups
+    land in a device cloud through the library's own transfer (two ranks need two GPUs: the driver's run)."""
+    assert "python native route ok" in _run_child(_PY_NATIVE_ROUTE)
+
+
 def _two_rank_worker(rank, port, out_dir):
     import torch
     import torch.distributed as dist

@@ -1,9 +1,8 @@
 """Kernel variants that the default benchmark shapes do not reach, against the CPU oracle:
   * the matrix-core column pass of the moment path (k_conv_col_mfma) on widths that are not a multiple of 4 (scalar staging),
     odd radii (slack rows), radii that need the 14-round and the unrolled-less staging variants;
-  * both column-pass kernels of the moment path at radii where the engine would pick the other one (PCR_HIP_TUNE_CONV = 1 / 2:
-    the one switch that is left; round 3 removed the _SCATTER / _B / _REC / _MOM experiment switches and the opt-in one-pass
-    sort together with the kernels behind them).
+  * the moment path at K = 3, 4, 5 on shapes with tiles and odd widths (round 5 removed the last experiment switch,
+    PCR_HIP_TUNE_CONV: each column-pass kernel is tested at the radii the engine runs it at, r < 24 vector ALU, r >= 24 matrix cores).
 Same tolerance as every Gaussian / Line test (rtol 1e-4, exact NaN mask)."""
 import os
 
@@ -76,20 +75,12 @@ def test_matrix_core_column_pass_shapes(A, case, rname):
     gaussian_case(A, case["G"], case["sigma"], case["maxr"], case["n"], tile=case.get("tile", (4096, 4096)), rname=rname)
 
 
-KNOBS = [
-    dict(PCR_HIP_TUNE_CONV=1),      # vector-ALU column pass at a radius the matrix cores would take
-    dict(PCR_HIP_TUNE_CONV=2),      # matrix cores at a radius the vector ALU would take
-]
-
-
-@pytest.mark.parametrize("knob", KNOBS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
-@pytest.mark.parametrize("shape", [dict(G=(300, 230), sigma=16.0, maxr=48.0, n=6000),               # K = 3
-                                   dict(G=(260, 200), sigma=4.0, maxr=12.0, n=8000, tile=(128, 96)),  # K = 5, r = 12
-                                   dict(G=(1301, 90), sigma=8.0, maxr=24.0, n=6000)],                 # K = 4: knobs of K = 3, 5 do not apply
+@pytest.mark.parametrize("shape", [dict(G=(300, 230), sigma=16.0, maxr=48.0, n=6000),               # K = 3, matrix cores
+                                   dict(G=(260, 200), sigma=4.0, maxr=12.0, n=8000, tile=(128, 96)),  # K = 5, r = 12, vector ALU
+                                   dict(G=(1301, 90), sigma=8.0, maxr=24.0, n=6000)],                 # K = 4, r = 24: the first matrix-core radius
                          ids=["s16", "s4_tiles", "s8_w1301"])
-def test_measurement_knobs_keep_the_moment_path_exact(A, knob, shape):
-    with env(**knob):
-        gaussian_case(A, shape["G"], shape["sigma"], shape["maxr"], shape["n"], tile=shape.get("tile", (4096, 4096)))
+def test_moment_path_orders_and_column_kernels(A, shape):
+    gaussian_case(A, shape["G"], shape["sigma"], shape["maxr"], shape["n"], tile=shape.get("tile", (4096, 4096)))
 
 
 def test_line_records_count_and_sum_exact(A):
