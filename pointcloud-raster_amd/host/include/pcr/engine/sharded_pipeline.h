@@ -53,6 +53,10 @@ public:
     /// The exchange alone (finalize() calls it): apron rows to their owners, touched-tile union.
     Status exchange();
     Status finalize();
+    /// `.pcrt` checkpoints: the exchange, then every rank writes / reads the tiles of its own rows (blocks of whole
+    /// reference-tile rows only -- align = tile height; the union of the ranks' files is an ordinary checkpoint).
+    Status save_state(const std::string& dir = "");
+    Status load_state(const std::string& dir = "") { return pipe_->load_state(dir); }
     const Grid* result() const { return pipe_->result(); }
     /// Collective, after finalize(): every rank's strip to `dst_rank` (pcr_hip_comm_gatherv, device to device), where *out
     /// becomes a host Grid of the WHOLE grid (width x height, the strips' bands); *out stays null on the other ranks.  The

@@ -687,38 +687,30 @@ struct Pipeline::Impl {
     }
 
     // ---- `.pcrt` checkpoints ---------------------------------------------------------------
+    // A whole-grid pipeline checkpoints every touched tile.  A row-block shard checkpoints the tiles it owns WHOLE -- which is
+    // all of them when its block is made of whole reference-tile rows (ShardedPipeline(align = tile_height); the N = 2 and 4
+    // blocks of C5): every rank then writes its own files into the same directory and their union is the pipeline's checkpoint,
+    // readable by an unsharded pipeline too.  A block that cuts tiles shares them with its neighbours and is refused.
     Status checkpoint_dir(const std::string& dir_in, std::string* dir) const {
         *dir = dir_in.empty() ? cfg.state_dir : dir_in;
         if (dir->empty()) return Status::error(StatusCode::InvalidArgument, "pipeline: no state directory given");
-        if (own_rows() != hg.height)
-            return Status::error(StatusCode::NotImplemented, "pipeline: tile-state checkpoints of a row-block shard are not supported");
+        if (own_rows() != hg.height && !block_is_whole_tiles())
+            return Status::error(StatusCode::NotImplemented,
+                "pipeline: tile-state checkpoints of a row-block shard need blocks of whole reference-tile rows (this block cuts a "
+                "tile it shares with a neighbour): shard with align = tile_height");
         return Status::success();
     }
-
-    // host copies of every group's planes + the touched flags
-    Status download_state(std::vector<std::vector<float>> (&hp)[4], std::vector<uint32_t>& touched) {
-        const size_t cells = (size_t)hg.width * hg.height;
-        {
-            Status ds = define_all_planes();
-            if (!ds.ok()) return ds;
-        }
-        for (int p = 0; p < 4; ++p) hp[p].assign(groups.size(), {});
-        for (size_t gi = 0; gi < groups.size(); ++gi)
-            for (int p = 0; p < 4; ++p) {
-                if (!(groups[gi].mask & kPlaneBits[p])) continue;
-                hp[p][gi].resize(cells);
-                Status s = detail::hip_status(pcr_hip_memcpy_d2h(hp[p][gi].data(), groups[gi].planes[p].data(),
-                                                                  cells * sizeof(float), stream));
-                if (!s.ok()) return s;
-            }
-        uint32_t* d_touched = nullptr;
-        int tx = 0, ty = 0;
-        Status s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, &tx, &ty));
-        if (!s.ok()) return s;
-        touched.resize((size_t)tx * ty);
-        s = detail::hip_status(pcr_hip_memcpy_d2h(touched.data(), d_touched, touched.size() * 4, stream));
-        if (!s.ok()) return s;
-        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+    detail::StateWindow state_window(std::vector<std::vector<float>>& planes) const {
+        detail::StateWindow w;
+        w.row0 = hg.state_row0;
+        w.rows = hg.state_rows;
+        w.own_row0 = hg.own_row0;
+        w.own_row1 = hg.own_row1;
+        w.plane = [&planes](int g, int p) -> float* {
+            auto& v = planes[(size_t)g * 4 + (size_t)p];
+            return v.empty() ? nullptr : v.data();
+        };
+        return w;
     }
 
     // The state WINDOW of this pipeline (any shard) as host copies: planes[4 g + p] (state_rows x W floats; empty when group g
@@ -780,47 +772,23 @@ struct Pipeline::Impl {
         std::string dir;
         Status s = checkpoint_dir(dir_in, &dir);
         if (!s.ok()) return s;
-        std::vector<std::vector<float>> hp[4];
+        std::vector<std::vector<float>> planes;
         std::vector<uint32_t> touched;
-        DeviceScope dev(cfg.cuda_device_id);
-        if (!(s = download_state(hp, touched)).ok()) return s;
-        detail::StateWindow w;
-        w.row0 = 0;
-        w.rows = hg.height;
-        w.plane = [&](int g, int p) -> float* { return hp[p][(size_t)g].empty() ? nullptr : hp[p][(size_t)g].data(); };
-        return detail::write_state_tiles(cfg.grid, state_outputs(), w, touched, dir);
+        if (!(s = export_window(planes, touched)).ok()) return s;
+        return detail::write_state_tiles(cfg.grid, state_outputs(), state_window(planes), touched, dir);
     }
 
     Status load_state(const std::string& dir_in) {
-        bands_stale();
         std::string dir;
         Status s = checkpoint_dir(dir_in, &dir);
         if (!s.ok()) return s;
-        std::vector<std::vector<float>> hp[4];
+        std::vector<std::vector<float>> planes;
         std::vector<uint32_t> touched;
-        DeviceScope dev(cfg.cuda_device_id);
-        if (!(s = download_state(hp, touched)).ok()) return s;
-        const GridConfig& g = cfg.grid;
-        detail::StateWindow w;
-        w.row0 = 0;
-        w.rows = hg.height;
-        w.plane = [&](int gi, int p) -> float* { return hp[p][(size_t)gi].empty() ? nullptr : hp[p][(size_t)gi].data(); };
+        if (!(s = export_window(planes, touched)).ok()) return s;          // files overlay the current state
         size_t loaded = 0;
-        if (!(s = detail::read_state_tiles(g, state_outputs(), w, touched, dir, &loaded)).ok()) return s;
+        if (!(s = detail::read_state_tiles(cfg.grid, state_outputs(), state_window(planes), touched, dir, &loaded)).ok()) return s;
         if (!loaded) return Status::success();
-        for (auto& gr : groups) gr.fresh = false;
-        const size_t cells = (size_t)g.width * g.height;
-        for (size_t gi = 0; gi < groups.size(); ++gi)
-            for (int p = 0; p < 4; ++p)
-                if (groups[gi].mask & kPlaneBits[p]) {
-                    s = detail::hip_status(pcr_hip_memcpy_h2d(groups[gi].planes[p].data(), hp[p][gi].data(),
-                                                              cells * sizeof(float), stream));
-                    if (!s.ok()) return s;
-                }
-        uint32_t* d_touched = nullptr;
-        if (!(s = detail::hip_status(pcr_hip_engine_tile_touched(engine, &d_touched, nullptr, nullptr))).ok()) return s;
-        if (!(s = detail::hip_status(pcr_hip_memcpy_h2d(d_touched, touched.data(), touched.size() * 4, stream))).ok()) return s;
-        return detail::hip_status(pcr_hip_stream_synchronize(stream));
+        return import_window(planes, touched);                              // (drops bands a scatter stored, marks the planes defined)
     }
 
     ProgressInfo stats() const {

@@ -22,7 +22,8 @@ TileRect tile_rect(const GridConfig& g, const StateWindow& w, int tx, int ty) {
     t.r0 = ty * g.tile_height;
     t.nc = std::min(g.tile_width, g.width - t.c0);
     t.nr = std::min(g.tile_height, g.height - t.r0);
-    t.inside = t.r0 >= w.row0 && t.r0 + t.nr <= w.row0 + w.rows;
+    const int lo = w.own_row0 >= 0 ? w.own_row0 : w.row0, hi = w.own_row0 >= 0 ? w.own_row1 : w.row0 + w.rows;
+    t.inside = t.r0 >= lo && t.r0 + t.nr <= hi && t.r0 >= w.row0 && t.r0 + t.nr <= w.row0 + w.rows;
     return t;
 }
 }  // namespace

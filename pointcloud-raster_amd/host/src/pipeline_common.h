@@ -100,6 +100,7 @@ inline Grouping group_reductions(const std::vector<ReductionSpec>& reductions) {
 // plane(group, p) -> rows x width floats, or null when the group has no plane p.
 struct StateWindow {
     int row0 = 0, rows = 0;
+    int own_row0 = -1, own_row1 = -1;      // >= 0: only tiles whose rows lie inside [own_row0, own_row1) (a shard with apron rows)
     std::function<float*(int group, int p)> plane;
 };
 

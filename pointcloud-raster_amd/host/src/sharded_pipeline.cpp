@@ -150,6 +150,12 @@ Status ShardedPipeline::finalize() {
     return write_geotiff(output_path_, *whole, grid_, GeoTiffOptions());
 }
 
+Status ShardedPipeline::save_state(const std::string& dir) {
+    Status s = exchange();                    // what the apron rows hold belongs in the neighbour's tiles
+    if (!s.ok()) return s;
+    return pipe_->save_state(dir);
+}
+
 Status ShardedPipeline::gather(int dst_rank, std::unique_ptr<Grid>* out) {
     if (!out) return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::gather: null result pointer");
     out->reset();

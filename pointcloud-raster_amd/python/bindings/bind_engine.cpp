@@ -224,6 +224,8 @@ void bind_engine(py::module_& m) {
         .def("ingest", [](ShardedPipeline& p, const PointCloud& c) { raise_if_error(p.ingest(c)); })
         .def("exchange", [](ShardedPipeline& p) { raise_if_error(p.exchange()); })
         .def("finalize", [](ShardedPipeline& p) { raise_if_error(p.finalize()); })
+        .def("save_state", [](ShardedPipeline& p, const std::string& dir) { raise_if_error(p.save_state(dir)); }, py::arg("dir") = "")
+        .def("load_state", [](ShardedPipeline& p, const std::string& dir) { raise_if_error(p.load_state(dir)); }, py::arg("dir") = "")
         .def("ingest_unrouted", [](ShardedPipeline& p, const PointCloud& c) {
             size_t got = 0;
             raise_if_error(p.ingest_unrouted(c, &got));

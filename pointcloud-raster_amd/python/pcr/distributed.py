@@ -556,6 +556,18 @@ class ShardedPipeline:
             if self.rank == 0:
                 pcr.write_geotiff(self.output_path, whole, self.grid)
 
+    def save_state(self, directory=""):
+        """`.pcrt` checkpoint of the sharded pipeline: the exchange first (what a rank's apron rows hold belongs in its
+        neighbour's tiles), then every rank writes the tiles it owns into `directory` -- their union is the checkpoint, readable
+        by an unsharded pipeline as well.  Needs blocks of whole reference-tile rows (align = tile_height): a tile cut by a
+        block edge has two owners and is refused (RuntimeError on the ranks concerned -- on all of them for even blocks)."""
+        self.exchange()
+        self.pipe.save_state(directory)
+
+    def load_state(self, directory=""):
+        """Every rank takes the tiles of its own rows from `directory` (also: PipelineConfig.resume at create)."""
+        self.pipe.load_state(directory)
+
     def result(self):
         """This rank's STRIP: rows [own[0], own[1]) of every band.  gather() assembles the whole grid on one rank."""
         return self.pipe.result()
