@@ -51,18 +51,23 @@ def build(seed):
     return og, specs, filt, clouds
 
 
-def to_cloud(c):
+def to_cloud(c, allow_device=True):
     pc = pcr.PointCloud.create(len(c["x"]))
     pc.set_x_array(c["x"])
     pc.set_y_array(c["y"])
     for name in ("a", "b", "cls", "dir"):
         pc.add_channel(name, pcr.DataType.Float32)
         pc.set_channel_array_f32(name, c[name])
-    return pc.to_device() if c["device"] else pc
+    return pc.to_device() if c["device"] and allow_device else pc
 
 
 @pytest.mark.parametrize("seed", range(40))
 def test_mixed_pipeline_matches_oracle(seed):
+    check_mixed_pipeline(seed, pcr.ExecutionMode.GPU, "hip")
+
+
+def check_mixed_pipeline(seed, exec_mode, engine):
+    """One random pipeline on the engine named (tests/test_host_engine_fuzz.py runs the same cases on the host engine)."""
     og, specs, filt, clouds = build(seed)
     cfg = pcr.PipelineConfig()
     cfg.grid.bounds = pcr.BBox(og.min_x, og.min_y, og.max_x, og.max_y)
@@ -70,7 +75,7 @@ def test_mixed_pipeline_matches_oracle(seed):
     cfg.grid.tile_width, cfg.grid.tile_height = og.tile_width, og.tile_height
     cfg.grid.compute_dimensions()
     assert (cfg.grid.width, cfg.grid.height) == (og.width, og.height)
-    cfg.exec_mode = pcr.ExecutionMode.GPU
+    cfg.exec_mode = exec_mode
     rs = []
     for i, s in enumerate(specs):
         if s["kind"] == "point":
@@ -90,8 +95,9 @@ def test_mixed_pipeline_matches_oracle(seed):
         cfg.filter = f
     pipe = pcr.Pipeline.create(cfg)
     assert pipe is not None, pcr.pipeline_create_error()
+    assert pipe.engine() == engine
     for c in clouds:
-        pipe.ingest(to_cloud(c))
+        pipe.ingest(to_cloud(c, allow_device=engine == "hip"))
     pipe.finalize()
     res = pipe.result()
     # the oracle sees the surviving points of all ingests at once (reductions are order-independent up to rounding)
