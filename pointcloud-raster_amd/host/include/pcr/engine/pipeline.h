@@ -149,6 +149,8 @@ public:
     int state_row_begin() const;
     int state_row_count() const;
     std::vector<PlaneView> state_planes() const;
+    /// Accumulation group of every ReductionSpec, in order (the `group` of state_planes()); empty on the other engines.
+    std::vector<int> reduction_groups() const;
     void* tile_touched_device(int* tiles_x, int* tiles_y) const;
     /// The same flags for READING only (nothing is assumed to change: bands a scatter stored stay valid).
     const void* tile_touched_device_readonly(int* tiles_x, int* tiles_y) const;

@@ -20,6 +20,7 @@
 #include <memory>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "pcr/engine/pipeline.h"
 
@@ -53,8 +54,10 @@ public:
     /// The exchange alone (finalize() calls it): apron rows to their owners, touched-tile union.
     Status exchange();
     Status finalize();
-    /// `.pcrt` checkpoints: the exchange, then every rank writes / reads the tiles of its own rows (blocks of whole
-    /// reference-tile rows only -- align = tile height; the union of the ranks' files is an ordinary checkpoint).
+    /// `.pcrt` checkpoints (collective).  save_state: the exchange first; with blocks of whole reference-tile rows every rank
+    /// writes the tiles it owns (their union is the checkpoint), with blocks that cut tiles the planes' owned rows are gathered
+    /// to rank 0, which writes the whole grid's tiles -- either way the files an unsharded pipeline would write.  load_state:
+    /// every rank takes its own rows out of the tile files they meet (also PipelineConfig::resume at create).
     Status save_state(const std::string& dir = "");
     Status load_state(const std::string& dir = "") { return pipe_->load_state(dir); }
     const Grid* result() const { return pipe_->result(); }
@@ -76,6 +79,8 @@ private:
     int rank_ = 0, world_ = 1, r0_ = 0, r1_ = 0, halo_ = 0, width_ = 0, height_ = 0, align_ = 1;
     GridConfig grid_;                 // the WHOLE grid
     std::string output_path_;         // taken from the configuration: rank 0 writes ONE GeoTIFF at finalize()
+    std::string state_dir_;
+    std::vector<ReductionSpec> reductions_;
     bool tiles_local_ = false;
     bool line_hl_groups_ = false;     // a Line group with a per-point half_length channel: ingest agrees on its reach first
 };

@@ -687,17 +687,18 @@ struct Pipeline::Impl {
     }
 
     // ---- `.pcrt` checkpoints ---------------------------------------------------------------
-    // A whole-grid pipeline checkpoints every touched tile.  A row-block shard checkpoints the tiles it owns WHOLE -- which is
-    // all of them when its block is made of whole reference-tile rows (ShardedPipeline(align = tile_height); the N = 2 and 4
-    // blocks of C5): every rank then writes its own files into the same directory and their union is the pipeline's checkpoint,
-    // readable by an unsharded pipeline too.  A block that cuts tiles shares them with its neighbours and is refused.
-    Status checkpoint_dir(const std::string& dir_in, std::string* dir) const {
+    // A whole-grid pipeline checkpoints every touched tile.  A row-block shard WRITES the tiles it owns whole -- which is all
+    // of them when its block is made of whole reference-tile rows (ShardedPipeline(align = tile_height); the N = 2 and 4 blocks
+    // of C5): every rank writes its own files into the same directory and their union is the pipeline's checkpoint, readable
+    // by an unsharded pipeline too.  A block that cuts tiles shares them with its neighbours: ShardedPipeline::save_state
+    // gathers the state to one rank for those.  Any shard LOADS: it takes its own rows out of every tile file they meet.
+    Status checkpoint_dir(const std::string& dir_in, std::string* dir, bool writing) const {
         *dir = dir_in.empty() ? cfg.state_dir : dir_in;
         if (dir->empty()) return Status::error(StatusCode::InvalidArgument, "pipeline: no state directory given");
-        if (own_rows() != hg.height && !block_is_whole_tiles())
+        if (writing && own_rows() != hg.height && !block_is_whole_tiles())
             return Status::error(StatusCode::NotImplemented,
-                "pipeline: tile-state checkpoints of a row-block shard need blocks of whole reference-tile rows (this block cuts a "
-                "tile it shares with a neighbour): shard with align = tile_height");
+                "pipeline: this row block cuts a reference tile it shares with a neighbour, so no rank can write that tile alone: "
+                "ShardedPipeline.save_state gathers the state for it, or shard with align = tile_height");
         return Status::success();
     }
     detail::StateWindow state_window(std::vector<std::vector<float>>& planes) const {
@@ -770,7 +771,7 @@ struct Pipeline::Impl {
 
     Status save_state(const std::string& dir_in) {
         std::string dir;
-        Status s = checkpoint_dir(dir_in, &dir);
+        Status s = checkpoint_dir(dir_in, &dir, true);
         if (!s.ok()) return s;
         std::vector<std::vector<float>> planes;
         std::vector<uint32_t> touched;
@@ -780,7 +781,7 @@ struct Pipeline::Impl {
 
     Status load_state(const std::string& dir_in) {
         std::string dir;
-        Status s = checkpoint_dir(dir_in, &dir);
+        Status s = checkpoint_dir(dir_in, &dir, false);
         if (!s.ok()) return s;
         std::vector<std::vector<float>> planes;
         std::vector<uint32_t> touched;
@@ -1294,6 +1295,13 @@ std::vector<Pipeline::PlaneView> Pipeline::state_planes() const {
             if (impl_->groups[g].mask & kPlaneBits[p])
                 out.push_back({impl_->groups[g].planes[p].data(), (int)kPlaneBits[p], (int)g,
                                impl_->groups[g].glyph.type == GlyphType::Point ? 0 : impl_->halo});
+    return out;
+}
+
+std::vector<int> Pipeline::reduction_groups() const {
+    std::vector<int> out;
+    if (banded_ || host_) return out;
+    for (const auto& o : impl_->outputs) out.push_back(o.group);
     return out;
 }
 

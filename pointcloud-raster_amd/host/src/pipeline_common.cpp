@@ -68,6 +68,11 @@ Status read_state_tiles(const GridConfig& g, const std::vector<StateOutput>& out
                         std::vector<uint32_t>& touched, const std::string& dir, size_t* loaded) {
     const int tiles_x = (g.width + g.tile_width - 1) / g.tile_width;
     const int tiles_y = (g.height + g.tile_height - 1) / g.tile_height;
+    // rows this window takes from the files: its own rows (a shard never loads into its apron), else the whole window.  A
+    // tile that the range only CUTS is read whole and its rows inside the range are taken: a row-block shard resumes from any
+    // checkpoint of the grid, whoever wrote it.
+    const int lo = w.own_row0 >= 0 ? std::max(w.own_row0, w.row0) : w.row0;
+    const int hi = w.own_row0 >= 0 ? std::min(w.own_row1, w.row0 + w.rows) : w.row0 + w.rows;
     std::vector<float> buf;
     size_t taken = 0;
     for (size_t r = 0; r < outputs.size(); ++r) {
@@ -77,7 +82,8 @@ Status read_state_tiles(const GridConfig& g, const std::vector<StateOutput>& out
         for (int ty = 0; ty < tiles_y; ++ty)
             for (int tx = 0; tx < tiles_x; ++tx) {
                 const TileRect t = tile_rect(g, w, tx, ty);
-                if (!t.inside) continue;
+                const int y0 = std::max(t.r0, lo), y1 = std::min(t.r0 + t.nr, hi);
+                if (y0 >= y1) continue;
                 TileIndex ti;
                 ti.row = ty;
                 ti.col = tx;
@@ -94,8 +100,8 @@ Status read_state_tiles(const GridConfig& g, const std::vector<StateOutput>& out
                 for (int f = 0; f < k; ++f) {
                     float* plane = w.plane(outputs[r].group, pl[f]);
                     if (!plane) return Status::error(StatusCode::InvalidArgument, "pipeline: a reduction's state plane is missing");
-                    for (int y = 0; y < t.nr; ++y)
-                        std::copy_n(buf.data() + ((size_t)f * t.nr + y) * t.nc, t.nc, plane + (size_t)(t.r0 - w.row0 + y) * g.width + t.c0);
+                    for (int y = y0; y < y1; ++y)
+                        std::copy_n(buf.data() + ((size_t)f * t.nr + (y - t.r0)) * t.nc, t.nc, plane + (size_t)(y - w.row0) * g.width + t.c0);
                 }
                 touched[(size_t)ty * tiles_x + tx] = 1;
                 ++taken;

@@ -11,6 +11,7 @@
 #include "pcr/core/point_cloud.h"
 #include "pcr/io/grid_io.h"
 #include "pcr_hip.h"
+#include "pipeline_common.h"
 
 namespace pcr {
 
@@ -53,6 +54,8 @@ std::unique_ptr<ShardedPipeline> ShardedPipeline::create(PipelineConfig cfg, con
     // src/engine/pipeline.cpp:1351-1361) -- not a strip per rank under the same name
     sp->output_path_ = cfg.output_path;
     cfg.output_path.clear();
+    sp->state_dir_ = cfg.state_dir;
+    sp->reductions_ = cfg.reductions;
     sp->pipe_ = Pipeline::create(cfg);
     if (!sp->pipe_) {
         g_create_error = "ShardedPipeline: " + pipeline_create_error();
@@ -150,10 +153,55 @@ Status ShardedPipeline::finalize() {
     return write_geotiff(output_path_, *whole, grid_, GeoTiffOptions());
 }
 
-Status ShardedPipeline::save_state(const std::string& dir) {
+Status ShardedPipeline::save_state(const std::string& dir_in) {
     Status s = exchange();                    // what the apron rows hold belongs in the neighbour's tiles
     if (!s.ok()) return s;
-    return pipe_->save_state(dir);
+    if (world_ == 1 || tiles_local_) return pipe_->save_state(dir_in);      // every tile has one owner: each rank writes its own
+    // Blocks that cut reference tiles: a tile has two owners and a `.pcrt` file holds a whole tile, so the owned rows of every
+    // plane travel to rank 0 (pcr_hip_comm_gatherv: the strips in rank order are the grid's rows in order), which writes the
+    // checkpoint of the whole grid -- the files an unsharded pipeline would have written.
+    const std::string dir = dir_in.empty() ? state_dir_ : dir_in;
+    if (dir.empty()) return Status::error(StatusCode::InvalidArgument, "pipeline: no state directory given");
+    void* stream = pipe_->stream_handle();
+    const std::vector<Pipeline::PlaneView> views = pipe_->state_planes();
+    const detail::Grouping grouping = detail::group_reductions(reductions_);
+    const uint64_t strip = (uint64_t)(r1_ - r0_) * (uint64_t)width_, whole = (uint64_t)height_ * (uint64_t)width_;
+    const bool root = rank_ == 0;
+    std::vector<std::vector<float>> planes(grouping.masks.size() * 4);
+    detail::Buffer landing;
+    Status local = root ? landing.allocate((size_t)whole * sizeof(float), MemoryLocation::Device) : Status::success();
+    for (const auto& v : views) {
+        int p = 0;
+        while (p < 4 && detail::kPlaneBits[p] != (uint32_t)v.plane_kind) ++p;
+        if (p == 4 || v.group < 0 || (size_t)v.group >= grouping.masks.size())
+            return Status::error(StatusCode::InvalidArgument, "ShardedPipeline::save_state: unknown plane");
+        const void* send[1] = {static_cast<const float*>(v.device_ptr) + (size_t)(r0_ - pipe_->state_row_begin()) * (size_t)width_};
+        void* recv[1] = {root && local.ok() ? landing.data() : nullptr};
+        const int32_t elem[1] = {4};
+        uint64_t counts[PCR_HIP_MAX_ROUTE_PARTS] = {};
+        s = detail::hip_status(pcr_hip_comm_gatherv(comm_, 1, send, recv, elem, strip, root ? whole : 0, counts, 0, stream));
+        if (!s.ok()) return local.ok() ? s : local;
+        if (!root) continue;
+        std::vector<float>& host = planes[(size_t)v.group * 4 + (size_t)p];
+        host.resize((size_t)whole);
+        if (!(s = detail::hip_status(pcr_hip_memcpy_d2h(host.data(), landing.data(), (size_t)whole * sizeof(float), stream))).ok()) return s;
+        if (!(s = detail::hip_status(pcr_hip_stream_synchronize(stream))).ok()) return s;     // (the landing area is reused)
+    }
+    if (!root) return Status::success();
+    int tx = 0, ty = 0;
+    const void* d_touched = pipe_->tile_touched_device_readonly(&tx, &ty);                    // the union, after the exchange
+    std::vector<uint32_t> touched((size_t)tx * (size_t)ty);
+    if (!d_touched) return Status::error(StatusCode::CudaError, "ShardedPipeline::save_state: no touched-tile flags");
+    if (!(s = detail::hip_status(pcr_hip_memcpy_d2h(touched.data(), d_touched, touched.size() * 4, stream))).ok()) return s;
+    if (!(s = detail::hip_status(pcr_hip_stream_synchronize(stream))).ok()) return s;
+    detail::StateWindow w;
+    w.row0 = 0;
+    w.rows = height_;
+    w.plane = [&planes](int g, int p) -> float* {
+        auto& v = planes[(size_t)g * 4 + (size_t)p];
+        return v.empty() ? nullptr : v.data();
+    };
+    return detail::write_state_tiles(grid_, grouping.outputs, w, touched, dir);
 }
 
 Status ShardedPipeline::gather(int dst_rank, std::unique_ptr<Grid>* out) {

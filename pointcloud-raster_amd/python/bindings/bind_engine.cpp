@@ -155,6 +155,7 @@ void bind_engine(py::module_& m) {
                 out.append(py::make_tuple(reinterpret_cast<uintptr_t>(v.device_ptr), v.plane_kind, v.group));
             return out;
         })
+        .def("reduction_groups", &Pipeline::reduction_groups, "Accumulation group of every ReductionSpec (the group of state_planes())")
         .def("plane_reach_rows", [](const Pipeline& p) {
             py::list out;                       // aligned with state_planes(): 0 = the plane's halo rows stay empty (Point glyph)
             for (const auto& v : p.state_planes()) out.append(v.reach_rows);

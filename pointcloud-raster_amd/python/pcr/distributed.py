@@ -314,6 +314,8 @@ class ShardedPipeline:
         # ONE file for the whole grid, written by rank 0 from the gathered strips (the reference writes one file,
         # src/engine/pipeline.cpp:1351-1361) -- not a strip per rank under the same name
         self.output_path, cfg.output_path = cfg.output_path, ""
+        self._state_dir = cfg.state_dir
+        self._rtypes = [r.type for r in cfg.reductions]
         if device_id is not None:
             cfg.cuda_device_id = device_id
         self.pipe = pcr.Pipeline.create(cfg)
@@ -557,12 +559,47 @@ class ShardedPipeline:
                 pcr.write_geotiff(self.output_path, whole, self.grid)
 
     def save_state(self, directory=""):
-        """`.pcrt` checkpoint of the sharded pipeline: the exchange first (what a rank's apron rows hold belongs in its
-        neighbour's tiles), then every rank writes the tiles it owns into `directory` -- their union is the checkpoint, readable
-        by an unsharded pipeline as well.  Needs blocks of whole reference-tile rows (align = tile_height): a tile cut by a
-        block edge has two owners and is refused (RuntimeError on the ranks concerned -- on all of them for even blocks)."""
+        """`.pcrt` checkpoint of the sharded pipeline (collective): the exchange first (what a rank's apron rows hold belongs
+        in its neighbour's tiles).  Blocks of whole reference-tile rows (align = tile_height): every rank writes the tiles it
+        owns, their union is the checkpoint.  Blocks that cut tiles: a tile has two owners and a file holds a whole tile, so
+        the planes' owned rows are gathered to rank 0, which writes the whole grid's tiles.  Either way the files are those an
+        unsharded pipeline would write (and reads back: resume at any world size)."""
         self.exchange()
-        self.pipe.save_state(directory)
+        if self.world == 1 or self.tiles_local:
+            return self.pipe.save_state(directory)
+        import os
+        import numpy as np
+        import pcr
+        directory = directory or self._state_dir
+        if not directory:
+            raise RuntimeError("pipeline: no state directory given")
+        rows_state, s0 = self.pipe.state_row_count(), self.pipe.state_row_begin()
+        o0, o1 = self.own
+        keys, strips = [], []
+        for ptr, kind, group in self.pipe.state_planes():
+            t = torch.as_tensor(pcr.DeviceArrayView(ptr, (rows_state, self.width), "<f4", owner=self.pipe), device="cuda")
+            keys.append((group, kind))
+            strips.append(t[o0 - s0:o1 - s0])
+        planes = self._gather_rows(0, strips)
+        ptr, tx, ty = self.pipe.tile_touched_ptr(readonly=True)                  # the union, after the exchange
+        touched = torch.as_tensor(pcr.DeviceArrayView(ptr, (ty, tx), "<i4", owner=self.pipe), device="cuda").cpu().numpy()
+        if self.rank != 0:
+            return
+        T = pcr.ReductionType
+        fields = {T.Sum: (PLANE_SUM,), T.Count: (PLANE_WGT,), T.Max: (PLANE_MAX,), T.Min: (PLANE_MIN,)}       # builtin_ops.h state layouts
+        g = self.grid
+        groups = self.pipe.reduction_groups()
+        for r, (grp, rtype) in enumerate(zip(groups, self._rtypes)):
+            state = np.stack([planes[keys.index((grp, k))] for k in fields.get(rtype, (PLANE_SUM, PLANE_WGT))])
+            rdir = directory if len(groups) == 1 else os.path.join(directory, f"reduction_{r}")
+            os.makedirs(rdir, exist_ok=True)
+            for row in range(ty):
+                for col in range(tx):
+                    if not touched[row, col]:
+                        continue
+                    r0, c0 = row * g.tile_height, col * g.tile_width
+                    tile = state[:, r0:min(r0 + g.tile_height, g.height), c0:min(c0 + g.tile_width, g.width)]
+                    pcr.write_tile_state(pcr.tile_state_filename(rdir, row, col), row, col, np.ascontiguousarray(tile), rtype)
 
     def load_state(self, directory=""):
         """Every rank takes the tiles of its own rows from `directory` (also: PipelineConfig.resume at create)."""
@@ -572,12 +609,64 @@ class ShardedPipeline:
         """This rank's STRIP: rows [own[0], own[1]) of every band.  gather() assembles the whole grid on one rank."""
         return self.pipe.result()
 
+    def _gather_rows(self, dst_rank, strips):
+        """Collective: `strips` = this rank's owned rows of some arrays (tensors [rows, W]: device tensors, or host tensors
+        over gloo); returns, on dst_rank, the list of assembled [H, W] float32 numpy arrays (None elsewhere).  The strips in
+        rank order are the grid's rows in order.  comm = "native": pcr_hip_comm_gatherv, device to device, up to eight arrays
+        per grouped round; comm = "torch": send / recv (nccl: from HBM; gloo: staged through host memory)."""
+        import numpy as np
+        W, H = self.width, self.grid.height
+        root = self.rank == dst_rank
+        rows = self.own[1] - self.own[0]
+        out = []
+        if self._comm is not None:
+            import ctypes as C
+            from . import _cabi as A
+            L = A.lib()
+            stream, ctx = self._engine_stream()
+            per_round = max(1, min(8, (4 << 30) // max(H * W * 4, 1)))
+            with ctx:
+                for b0 in range(0, len(strips), per_round):
+                    part = [t if t.is_cuda else t.cuda() for t in strips[b0:b0 + per_round]]
+                    k = len(part)
+                    land = torch.empty((k, H, W), dtype=torch.float32, device="cuda") if root else None
+                    srcs = (C.c_void_p * k)(*[t.data_ptr() for t in part])
+                    dsts = (C.c_void_p * k)(*[land[a].data_ptr() if root else None for a in range(k)])
+                    elems = (C.c_int32 * k)(*([4] * k))
+                    A.check(L.pcr_hip_comm_gatherv(self._comm, k, srcs, dsts, elems, rows * W, H * W if root else 0, None,
+                                                   dst_rank, stream))
+                    if root:
+                        host = land.cpu()                    # (on this stream: after the receives)
+                        out += [host[a].numpy() for a in range(k)]
+                if not stream:
+                    torch.cuda.current_stream().synchronize()
+            return out if root else None
+        stage = dist.get_backend(self.group) == "gloo"
+        if stage and not any(t.is_cuda for t in strips):
+            import contextlib
+            ctx = contextlib.nullcontext()           # host arrays over gloo: no device in the path at all
+        else:
+            _, ctx = self._engine_stream()
+        with ctx:
+            for t in strips:
+                mine = t.cpu() if stage else (t if t.is_cuda else t.cuda())
+                if root:
+                    full = torch.empty((H, W), dtype=torch.float32, device="cpu" if stage else "cuda")
+                    ops = [dist.P2POp(dist.irecv, full[b0:b1], r, self.group)
+                           for r, (b0, b1) in enumerate(self.blocks) if r != self.rank and b1 > b0]
+                    for req in (dist.batch_isend_irecv(ops) if ops else []):
+                        req.wait()
+                    full[self.own[0]:self.own[1]] = mine
+                    out.append(full.cpu().numpy())
+                elif rows > 0:
+                    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), dst_rank, self.group)]):
+                        req.wait()
+        return out if root else None
+
     def gather(self, dst_rank=0):
         """Collective, after finalize(): every rank's strip travels to `dst_rank`, which returns ONE host pcr.Grid of the whole
         grid (the strips in rank order are the grid's rows in order); the other ranks return None.  The reference's result()
-        is one grid (src/engine/pipeline.cpp:1175-1186).  comm = "native": pcr_hip_comm_gatherv, device to device (up to
-        eight bands per grouped round); comm = "torch": send / recv of the bands (nccl: from HBM; gloo: staged through host
-        memory)."""
+        is one grid (src/engine/pipeline.cpp:1175-1186).  Transport: _gather_rows."""
         import numpy as np
         import pcr
         res = self.pipe.result()
@@ -590,59 +679,19 @@ class ShardedPipeline:
         rows = self.own[1] - self.own[0]
         on_device = res.location() == pcr.MemoryLocation.Device
 
-        def strip_device(b):                       # this rank's band b as a device tensor (zero-copy)
-            ptr = self.pipe.result_band_device_ptr(b)
-            return torch.as_tensor(pcr.DeviceArrayView(ptr, (rows, W), "<f4", owner=self.pipe), device="cuda")
-
-        def strip_host(b):
-            return strip_device(b).cpu() if on_device else torch.from_numpy(np.array(res.band_array(b)))
+        def strip(b):                              # this rank's band b: a zero-copy device view, or the host band
+            ptr = self.pipe.result_band_device_ptr(b) if hasattr(self.pipe, "result_band_device_ptr") else 0
+            if ptr and (on_device or self._comm is not None or dist.get_backend(self.group) != "gloo"):
+                return torch.as_tensor(pcr.DeviceArrayView(ptr, (rows, W), "<f4", owner=self.pipe), device="cuda")
+            return torch.from_numpy(np.array(res.band_array(b)))
 
         whole = pcr.Grid.create(W, H, [res.band_desc(b) for b in range(nb)]) if root else None
         if self.world == 1:
             for b in range(nb):
-                whole.set_band_array(b, strip_host(b).numpy())
+                whole.set_band_array(b, strip(b).cpu().numpy())
             return whole
-        if self._comm is not None:
-            import ctypes as C
-            from . import _cabi as A
-            L = A.lib()
-            stream, ctx = self._engine_stream()
-            per_round = max(1, min(8, (4 << 30) // max(H * W * 4, 1)))
-            with ctx:
-                for b0 in range(0, nb, per_round):
-                    k = min(per_round, nb - b0)
-                    land = torch.empty((k, H, W), dtype=torch.float32, device="cuda") if root else None
-                    strips = [strip_device(b0 + a) for a in range(k)]
-                    srcs = (C.c_void_p * k)(*[t.data_ptr() for t in strips])
-                    dsts = (C.c_void_p * k)(*[land[a].data_ptr() if root else None for a in range(k)])
-                    elems = (C.c_int32 * k)(*([4] * k))
-                    A.check(L.pcr_hip_comm_gatherv(self._comm, k, srcs, dsts, elems, rows * W, H * W if root else 0, None,
-                                                   dst_rank, stream))
-                    if root:
-                        host = land.cpu()                    # (on this stream: after the receives)
-                        for a in range(k):
-                            whole.set_band_array(b0 + a, host[a].numpy())
-                if not stream:
-                    torch.cuda.current_stream().synchronize()
-            return whole
-        stage = dist.get_backend(self.group) == "gloo"
-        if stage and not on_device:
-            import contextlib
-            ctx = contextlib.nullcontext()           # host bands over gloo: no device in the path at all
-        else:
-            _, ctx = self._engine_stream()
-        with ctx:
+        bands = self._gather_rows(dst_rank, [strip(b) for b in range(nb)])
+        if root:
             for b in range(nb):
-                mine = strip_host(b) if stage else strip_device(b)
-                if root:
-                    full = torch.empty((H, W), dtype=torch.float32, device="cpu" if stage else "cuda")
-                    ops = [dist.P2POp(dist.irecv, full[b0:b1], r, self.group)
-                           for r, (b0, b1) in enumerate(self.blocks) if r != self.rank and b1 > b0]
-                    for req in (dist.batch_isend_irecv(ops) if ops else []):
-                        req.wait()
-                    full[self.own[0]:self.own[1]] = mine
-                    whole.set_band_array(b, full.cpu().numpy())
-                elif rows > 0:
-                    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), dst_rank, self.group)]):
-                        req.wait()
+                whole.set_band_array(b, bands[b])
         return whole

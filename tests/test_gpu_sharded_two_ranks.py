@@ -317,22 +317,34 @@ def _worker_checkpoint(rank, world, port, out_dir):
         b.ingest(cloud_of(1))
         b.finalize()
         out = {f"b{i}": np.array(b.result().band_array(i)) for i in range(4)}
-        # a block that cuts a tile cannot checkpoint it: refused, with the way out in the message
+        # blocks that CUT tiles (tile height 64, blocks of 60 rows): a tile has two owners -- the owned rows of every plane are
+        # gathered to rank 0, which writes the whole grid's tiles; the shards that resume take their own rows out of them
+        ck2 = os.path.join(out_dir, "ck_cut")
         c = ShardedPipeline(cfg_for(64), rank, world, device_id=0)
+        assert not c.tiles_local
+        c.ingest(cloud_of(0))
+        c.save_state(ck2)
+        dist.barrier()
         try:
-            c.save_state(os.path.join(out_dir, "never"))
+            c.pipe.save_state(os.path.join(out_dir, "never"))          # one rank alone cannot
             out["refused"] = np.array(0)
         except RuntimeError as exc:
             out["refused"] = np.array(int("align = tile_height" in str(exc)))
+        d = ShardedPipeline(cfg_for(64, state_dir=ck2, resume=True), rank, world, device_id=0)
+        d.ingest(cloud_of(1))
+        d.finalize()
+        for i in range(4):
+            out[f"cut{i}"] = np.array(d.result().band_array(i))
         np.savez(os.path.join(out_dir, f"c{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_checkpoint_and_resume_with_tile_aligned_blocks(tmp_path):
-    """`.pcrt` checkpoints of a sharded pipeline (VERDICT r04 missing 3): blocks of whole reference-tile rows -> every rank
+def test_two_rank_checkpoint_and_resume(tmp_path):
+    """`.pcrt` checkpoints of a sharded pipeline (VERDICT r04 missing 3).  Blocks of whole reference-tile rows: every rank
     writes the tiles it owns, the union is an ordinary checkpoint; resumed by two new shards AND by one unsharded pipeline,
-    second cloud ingested, all equal to the oracle over both clouds."""
+    second cloud ingested, all equal to the oracle over both clouds.  Blocks that cut tiles: the state is gathered to rank 0,
+    which writes the tiles; the resuming shards take their own rows out of the files."""
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "pointcloud-raster_amd", "python"))
@@ -375,3 +387,13 @@ def test_two_rank_checkpoint_and_resume_with_tile_aligned_blocks(tmp_path):
             assert np.array_equal(np.isnan(got), np.isnan(w)), f"{name}, band {b}: NaN mask"
             m = ~np.isnan(w)
             assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"{name}, band {b}"
+    # the cut-tile checkpoint: 2 x 3 tiles of 64 rows written by rank 0 alone, resumed by two shards of 60 rows
+    assert sorted(os.listdir(tmp_path / "ck_cut" / "reduction_3")) == [f"tile_{r:04d}_{c:04d}.pcrt" for r in range(2) for c in range(3)]
+    og64 = O.make_grid((0, 0, G_W, G_H), tile=(64, 64))
+    want64 = [O.run(og64, O.WEIGHTED_AVERAGE, X, Y, V, glyph=gg), O.run(og64, O.SUM, X, Y, V, glyph=gg),
+              O.run(og64, O.WEIGHTED_AVERAGE, X, Y, V, glyph=lg, direction=D), O.run(og64, O.COUNT, X, Y, V, glyph=lg, direction=D)]
+    for b, (rt, at) in enumerate([(1e-4, 1e-6), (1e-4, 1e-5), (1e-4, 1e-6), (0, 0)]):
+        got, w = np.vstack([parts[0][f"cut{b}"], parts[1][f"cut{b}"]]), want64[b]
+        assert np.array_equal(np.isnan(got), np.isnan(w)), f"cut tiles, band {b}: NaN mask"
+        m = ~np.isnan(w)
+        assert (np.abs(got[m] - w[m]) <= at + rt * np.abs(w[m])).all(), f"cut tiles, band {b}"
