@@ -204,3 +204,44 @@ def test_cell_tiles_at_the_launch_shape_of_the_r03c_fault(monkeypatch):
     assert not np.isnan(g).any() and not np.isnan(want).any()
     assert (np.abs(g.astype(np.float64) - want) <= 1e-4 * np.maximum(1e-3, np.abs(want))).all()
     assert np.isfinite(got).all()                                    # every cell of the grid is reached at ~3 points per cell
+
+
+def test_the_two_engines_agree_on_the_timed_cloud_at_full_size():
+    """The product's two engines on BASELINE configs[1]'s cloud (50 M points, 4096^2, Sum + Count + Average): the HIP engine
+    and the host engine behind ExecutionMode.CPU share no code -- Count must be identical cell for cell, Sum and Average agree
+    to the tolerance each is tested to against the oracle (the host engine folds in f32 in point order, the HIP tiles in f64)."""
+    G, n = 4096, 50_000_000
+    rng = np.random.default_rng(42)
+    x, y = rng.uniform(2, G - 2, n), rng.uniform(2, G - 2, n)
+    v = rng.uniform(0, 1, n).astype(np.float32)
+    bands = {}
+    for mode, engine in ((pcr.ExecutionMode.GPU, "hip"), (pcr.ExecutionMode.CPU, "host")):
+        cfg = pcr.PipelineConfig()
+        cfg.grid.bounds = pcr.BBox(0.0, 0.0, float(G), float(G))
+        cfg.grid.cell_size_x, cfg.grid.cell_size_y = 1.0, -1.0
+        cfg.grid.compute_dimensions()
+        cfg.exec_mode = mode
+        specs = []
+        for t in (pcr.ReductionType.Sum, pcr.ReductionType.Count, pcr.ReductionType.Average):
+            r = pcr.ReductionSpec()
+            r.value_channel, r.type = "value", t
+            specs.append(r)
+        cfg.reductions = specs
+        pipe = pcr.Pipeline.create(cfg)
+        assert pipe is not None and pipe.engine() == engine, pcr.pipeline_create_error()
+        cloud = pcr.PointCloud.create(n)
+        cloud.set_x_array(x)
+        cloud.set_y_array(y)
+        cloud.add_channel("value", pcr.DataType.Float32)
+        cloud.set_channel_array_f32("value", v)
+        pipe.ingest(cloud)
+        pipe.finalize()
+        bands[engine] = [np.array(pipe.result().band_array(b)) for b in range(3)]
+        assert pipe.stats().points_processed == n
+    assert np.array_equal(bands["hip"][1], bands["host"][1], equal_nan=True)                     # Count: bit for bit
+    assert float(np.nansum(bands["hip"][1].astype(np.float64))) == n
+    for b in (0, 2):
+        a, c = bands["hip"][b], bands["host"][b]
+        assert np.array_equal(np.isnan(a), np.isnan(c))
+        m = ~np.isnan(a)
+        assert (np.abs(a[m] - c[m]) <= 2e-5 * np.maximum(1.0, np.abs(a[m]))).all(), b
