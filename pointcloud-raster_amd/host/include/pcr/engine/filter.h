@@ -1,6 +1,6 @@
 // pcr/engine/filter.h -- point filter specification (API parity with the reference's
-// include/pcr/engine/filter.h).  The filter stage itself is outside the accelerated path of
-// this build: a pipeline configured with a non-empty FilterSpec refuses to ingest.
+// include/pcr/engine/filter.h).  Both engines evaluate it before routing: a byte mask on the device
+// (pcr_hip_filter_mask), a host loop in the host engine; a filtered-out point exists for no reduction.
 #pragma once
 
 #include "pcr/core/types.h"

@@ -2,8 +2,10 @@
 
 Drop-in for the reference `pcr` package (python/pcr/__init__.py): same classes, enums and
 helper functions, backed by hand-written HIP kernels through the C-ABI of include/pcr_hip.h.
-There is no CPU engine behind this module: `Pipeline.create` returns None (and prints why)
-when no GPU is usable or ExecutionMode.CPU is requested.
+ExecutionMode.GPU / Auto / Hybrid run the HIP engine; ExecutionMode.CPU -- and the cases in which the
+reference falls back to its CPU mode, after the reference's own Warning / Info line -- run the host
+engine (`Pipeline.engine()` says which; PCR_REQUIRE_GPU_ENGINE=1 forbids every fallback).  The module
+itself does not import without libpcr_hip.so.
 """
 import os as _os
 
