@@ -986,21 +986,54 @@ struct Pipeline::Banded {
             staged = cloud.to(MemoryLocation::Device);
             if (staged) src = staged.get();
         }
+        // Which bands does this cloud reach at all?  One routing pass over x, y (pcr_hip_route_count with the bands as the parts:
+        // 16 B per point, ~0.2 ms per 100 M points) against ~50 ms per band VISITED (a sub-pipeline, the band's state over
+        // PCIe both ways: profiles/r05_out_of_core_cost.md) -- a survey tile that covers a corner of the grid then costs its
+        // own bands only.  (The filter is not applied: a superset of the kept points, so no band is skipped wrongly.)
+        std::vector<uint64_t> reach(bands.size(), 1);
+        size_t valid_total = 0;
+        if (bands.size() <= PCR_HIP_MAX_ROUTE_PARTS && src->location() == MemoryLocation::Device) {
+            Impl::DeviceScope dev(cfg.cuda_device_id);
+            const GridConfig& g = cfg.grid;
+            pcr_hip_grid hg{};
+            hg.min_x = g.bounds.min_x; hg.min_y = g.bounds.min_y; hg.max_x = g.bounds.max_x; hg.max_y = g.bounds.max_y;
+            hg.cell_size_x = g.cell_size_x; hg.cell_size_y = g.cell_size_y;
+            hg.width = g.width; hg.height = g.height; hg.tile_width = g.tile_width; hg.tile_height = g.tile_height;
+            hg.own_row0 = 0; hg.own_row1 = g.height; hg.state_row0 = 0; hg.state_rows = g.height;
+            std::vector<int32_t> splits;
+            for (const auto& bd : bands) splits.push_back(bd.first);
+            splits.push_back(bands.back().second);
+            detail::Buffer dest, counts;
+            std::vector<uint64_t> host(bands.size(), 0);
+            if (dest.allocate(src->count(), MemoryLocation::Device).ok() && counts.allocate(bands.size() * 8, MemoryLocation::Device).ok() &&
+                pcr_hip_route_count(&hg, splits.data(), (int)bands.size(), src->x(), src->y(), nullptr, src->count(),
+                                    static_cast<uint8_t*>(dest.data()), static_cast<unsigned long long*>(counts.data()), nullptr) == PCR_HIP_OK &&
+                pcr_hip_memcpy_d2h(host.data(), counts.data(), host.size() * 8, nullptr) == PCR_HIP_OK &&
+                pcr_hip_stream_synchronize(nullptr) == PCR_HIP_OK)
+                reach = host;
+        }
         for (size_t b = 0; b < bands.size(); ++b) {
+            if (reach[b] == 0) continue;                                    // none of this cloud's points has its centre row here
             Status s = Status::success();
-            std::unique_ptr<Pipeline> sub = visit(b, &s);
+            bool from_disk = false;
+            std::unique_ptr<Pipeline> sub = visit(b, &s, &from_disk);
             if (!sub) return s;
             if (!(s = sub->ingest(*src)).ok()) return s;
-            last = sub->last_scatter();
-            if (!parked[b].any && last.points_valid == 0) continue;        // nothing of this cloud (or any before) fell here
+            const ScatterInfo here = sub->last_scatter();
+            valid_total += here.points_valid;
+            last = here;
+            if (!parked[b].any && here.points_valid == 0) continue;        // nothing of this cloud (or any before) fell here
             Parked& k = parked[b];
-            if (last.points_valid == 0 && k.any) {                           // unchanged: the parked copy (and its files) stay current
-                if (!(s = evict()).ok()) return s;
+            if (here.points_valid == 0 && k.any) {                           // unchanged: the parked copy (and its files) stay current
+                if (from_disk) drop_host_copy(b);
+                else if (!(s = evict()).ok()) return s;
                 continue;
             }
             if (!(s = sub->impl_->export_window(k.planes, k.touched)).ok()) return s;
             if (!(s = account(b)).ok()) return s;
         }
+        last.points_in = cloud.count();                                     // (of the whole ingest: every band saw every point)
+        last.points_valid = valid_total;
         ++collections;
         points += cloud.count();
         if (callback) {

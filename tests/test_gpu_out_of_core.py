@@ -104,6 +104,7 @@ def test_untouched_bands_stay_nan_and_cost_no_parking(tmp_path):
     p = pcr.Pipeline.create(config_for(og, [spec("Sum")], gpu_memory_budget=1 << 20, host_cache_budget=1, state_dir=str(tmp_path)))
     assert p is not None and p.out_of_core()
     p.ingest(cloud_from(x, y, {"value": v}, "device"))
+    assert p.last_scatter()["points_valid"] == n                       # over all bands (three of the four were not even visited)
     assert sorted(os.listdir(p.spill_dir())) == [f"tile_0000_{c:04d}.pcrt" for c in range(4)]  # one reduction: the reference's flat layout
     p.finalize()
     got = bands_of(p)[0]

@@ -43,13 +43,13 @@ dev = cloud.to_device()
 del cloud
 
 
-def run(label, **kw):
+def run(label, the_cloud=None, **kw):
     p = pcr.Pipeline.create(cfg(**kw))
     assert p is not None, pcr.pipeline_create_error()
     times = []
     for _ in range(3):                       # three ingests of the same cloud into one pipeline
         t0 = time.perf_counter()
-        p.ingest(dev)
+        p.ingest(the_cloud if the_cloud is not None else dev)
         p.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     t0 = time.perf_counter()
@@ -73,10 +73,23 @@ try:
     # 1.2 GB budget: one 4096-row tile row (805 MB of planes + band) per band -> 4 bands
     res["runs"].append(run("out of core, 4 bands parked in host memory", gpu_memory_budget=1200 << 20, host_cache_budget=64 << 30, state_dir=tmp))
     res["runs"].append(run("out of core, 4 bands spilled to disk (.pcrt tiles)", gpu_memory_budget=1200 << 20, host_cache_budget=1, state_dir=tmp))
+    # a survey tile: the same number of points inside the top-left 4096 x 4096 cells -- one band of the four is reached
+    m = n // 4
+    c2 = pcr.PointCloud.create(m)
+    c2.set_x_array(rng.uniform(2, 4094, m))
+    c2.set_y_array(rng.uniform(G - 4094, G - 2, m))
+    c2.add_channel("value", pcr.DataType.Float32)
+    c2.set_channel_array_f32("value", rng.uniform(0, 1, m).astype(np.float32))
+    d2 = c2.to_device()
+    res["runs"].append(run(f"in core, {m} points inside one 4096^2 corner", the_cloud=d2))
+    res["runs"].append(run(f"out of core (host-parked), {m} points inside one 4096^2 corner: one band reached", the_cloud=d2,
+                           gpu_memory_budget=1200 << 20, host_cache_budget=64 << 30, state_dir=tmp))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
-base = res["runs"][0]
-for r in res["runs"][1:]:
+for i, r in enumerate(res["runs"]):
+    if not r["out_of_core"]:
+        base = r
+        continue
     r["bands"] = 4
     r["ms_per_ingest_per_band"] = round(sum(r["ingest_ms"][1:]) / 2 / 4, 1)
     r["same_result_as_in_core"] = r["checksum"] == base["checksum"]
