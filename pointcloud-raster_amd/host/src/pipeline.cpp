@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <filesystem>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <set>
@@ -1059,6 +1060,13 @@ struct Pipeline::Banded {
         tiles_active = 0;
         for (size_t b = 0; b < bands.size(); ++b) {
             Status s = Status::success();
+            if (!parked[b].any) {
+                // no point ever had its centre row here: every tile of the band is untouched, every band NaN (Q3) -- no visit
+                const size_t first = (size_t)bands[b].first * g.width, cells = (size_t)(bands[b].second - bands[b].first) * g.width;
+                for (size_t o = 0; o < descs.size(); ++o)
+                    std::fill_n(result->band_f32((int)o) + first, cells, std::numeric_limits<float>::quiet_NaN());
+                continue;
+            }
             bool from_disk = false;
             std::unique_ptr<Pipeline> sub = visit(b, &s, &from_disk);
             if (!sub) return s;

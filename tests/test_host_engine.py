@@ -86,7 +86,10 @@ def test_c1_as_written_one_million_points_average_cpu_mode():
 @pytest.mark.parametrize("threads", [1, 3, 8])
 def test_point_reductions_bit_for_bit_whatever_the_thread_count(threads):
     """All six ops on a multi-tile grid (Q2: Sum = 0.0 on empty cells of a touched tile; Q3: untouched tiles NaN), points on
-    the bounds (Q1: x == max_x lands in the last column), points outside, two ingests."""
+    the bounds (Q1: x == max_x lands in the last column), points outside, two ingests.  The reference's threading tests ask for
+    1 thread == max threads (tests/cpp/test_threading.cpp:53-95 Sum EXPECT_FLOAT_EQ, :97-144 Average within 1e-5, :146 Max / Min
+    deterministic, :419-447 cpu_threads reaches OpenMP, :449-549 the pipeline single- vs multi-threaded): here every band is the
+    SAME BITS at 1, 3 and 8 threads, because a cell folds its points in index order whoever owns its stripe."""
     W, H = 300, 200
     rng = np.random.default_rng(7)
     n = 60_000
@@ -97,6 +100,7 @@ def test_point_reductions_bit_for_bit_whatever_the_thread_count(threads):
     kinds = ["Sum", "Count", "Average", "WeightedAverage", "Max", "Min"]
     cfg.reductions = [spec(k) for k in kinds]
     pipe = pcr.Pipeline.create(cfg)
+    assert pipe.host_threads() == threads                              # cpu_threads reaches the engine (test_threading.cpp:419-447)
     half = (n + 4) // 2
     pipe.ingest(make_cloud(x[:half], y[:half], value=v[:half]))
     pipe.ingest(make_cloud(x[half:], y[half:], value=v[half:]))
