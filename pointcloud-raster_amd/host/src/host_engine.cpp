@@ -162,31 +162,25 @@ size_t HostEngine::route(const double* x, const double* y, const uint8_t* keep, 
     const double ox = g_.bounds.min_x, oy = g_.bounds.max_y, csx = g_.cell_size_x, csy = g_.cell_size_y;
     const double min_x = g_.bounds.min_x, max_x = g_.bounds.max_x, min_y = g_.bounds.min_y, max_y = g_.bounds.max_y;
     const int tw = g_.tile_width, th = g_.tile_height;
-    std::vector<std::vector<uint8_t>> seen((size_t)threads_);
     size_t valid = 0;
-#pragma omp parallel num_threads(threads_) reduction(+ : valid)
-    {
-        std::vector<uint8_t>& mine = seen[(size_t)omp_get_thread_num()];
-        mine.assign(touched_.size(), 0);
-#pragma omp for schedule(static)
-        for (int64_t i = 0; i < (int64_t)n; ++i) {
-            int c = 0, r = -1;
-            const double wx = x[i], wy = y[i];
-            if ((!keep || keep[i]) && wx >= min_x && wx <= max_x && wy >= min_y && wy <= max_y) {
-                c = static_cast<int>(std::floor((wx - ox) / csx));
-                r = static_cast<int>(std::floor((wy - oy) / csy));
-                c = std::max(0, std::min(c, W_ - 1));
-                r = std::max(0, std::min(r, H_ - 1));
-                mine[(size_t)(r / th) * tiles_x_ + (size_t)(c / tw)] = 1;
-                ++valid;
-            }
-            col_[(size_t)i] = c;
-            row_[(size_t)i] = r;
+    uint32_t* flags = touched_.data();
+#pragma omp parallel for num_threads(threads_) schedule(static) reduction(+ : valid)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        int c = 0, r = -1;
+        const double wx = x[i], wy = y[i];
+        if ((!keep || keep[i]) && wx >= min_x && wx <= max_x && wy >= min_y && wy <= max_y) {
+            c = static_cast<int>(std::floor((wx - ox) / csx));
+            r = static_cast<int>(std::floor((wy - oy) / csy));
+            c = std::max(0, std::min(c, W_ - 1));
+            r = std::max(0, std::min(r, H_ - 1));
+            // (every writer stores 1: a relaxed atomic store, so that threads marking the same tile do not race)
+            uint32_t* f = flags + (size_t)(r / th) * tiles_x_ + (size_t)(c / tw);
+            if (__atomic_load_n(f, __ATOMIC_RELAXED) == 0u) __atomic_store_n(f, 1u, __ATOMIC_RELAXED);
+            ++valid;
         }
+        col_[(size_t)i] = c;
+        row_[(size_t)i] = r;
     }
-    for (const auto& t : seen)
-        for (size_t k = 0; k < t.size(); ++k)
-            if (t[k]) touched_[k] = 1u;
     return valid;
 }
 

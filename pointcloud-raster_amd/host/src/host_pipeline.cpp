@@ -92,7 +92,8 @@ Status Pipeline::Host::ingest(const PointCloud& cloud_in) {
         keep.assign(n, 1);
         for (const auto& pr : cfg.filter.predicates) {
             const float* ch = cloud->channel_f32(pr.channel_name);
-#pragma omp parallel for schedule(static)
+            const int team = engine->threads();
+#pragma omp parallel for num_threads(team) schedule(static)
             for (int64_t i = 0; i < (int64_t)n; ++i) {
                 const float v = ch[i];
                 bool ok = false;
