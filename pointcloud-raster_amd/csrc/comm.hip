@@ -51,18 +51,19 @@ Rccl* rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         // ONE RCCL per process, and the one that belongs to the HIP runtime in use:
-        //  1. a copy the process has already loaded (torch's bundled librccl.so has no SONAME: it is known by that name);
-        //  2. PCR_HIP_RCCL = explicit path;
+        //  1. PCR_HIP_RCCL = explicit path: what the caller names wins (a site-specific build; the test double of
+        //     tests/native/fake_rccl.cpp, which lets several ranks share one GPU);
+        //  2. a copy the process has already loaded (torch's bundled librccl.so has no SONAME: it is known by that name);
         //  3. the sibling of the libamdhip64 this library is running on (torch/lib/librccl.so next to torch's runtime,
         //     /opt/rocm/lib/librccl.so.1 next to ROCm's) -- a second RCCL with its own rocm_smi / roctx copies next to
         //     the host's ends in a double free at process exit;
         //  4. the loader's search path.
-        for (const char* name : {"librccl.so", "librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-            if (r.lib) break;
+        if (const char* forced = std::getenv("PCR_HIP_RCCL")) {
+            if (forced[0]) r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!r.lib) {
-            if (const char* forced = std::getenv("PCR_HIP_RCCL")) r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
         }
         if (!r.lib) {
             Dl_info info;

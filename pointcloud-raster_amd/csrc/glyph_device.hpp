@@ -9,6 +9,8 @@
 // end points rounded half away from zero (Q7).
 #pragma once
 
+#include "libm_sincosf.hpp"
+
 #include "common.hpp"
 
 namespace pcrhip {
@@ -35,15 +37,11 @@ __device__ __forceinline__ PointGeom point_geom(const GridDev& g, double wx, dou
     return p;
 }
 
-// cosf/sinf as the host libm returns them: glibc's float routines evaluate in double and
-// round once, so (float)cos((double)a) reproduces them (differences would move a line's
-// rounded end point by a whole cell).
-__device__ __forceinline__ void sincos_like_libm(float a, float& s, float& c) {
-    double sd, cd;
-    sincos((double)a, &sd, &cd);
-    s = (float)sd;
-    c = (float)cd;
-}
+// cosf / sinf as the reference's host libm returns them -- glibc's own sincosf algorithm, restated in libm_sincosf.hpp and
+// compared with the system's libm bit for bit (tests/test_libm_sincosf.py): a last-bit difference moves a Line's rounded
+// end point by a whole cell now and then.  (Rounds 1-4 took (float)cos((double)a) for it; glibc's float routines are not
+// correctly rounded, and 2.7 % of random arguments differ -- the round-5 soak found the segment that showed it.)
+__device__ __forceinline__ void sincos_like_libm(float a, float& s, float& c) { libm::sincosf(a, s, c); }
 
 // Per-point channel values of a glyph (only the ones whose GlyphDev pointer is set are meaningful):
 // Gaussian: c0 = sigma_x, c1 = sigma_y, c2 = rotation; Line: c0 = direction, c1 = half_length.
@@ -301,7 +299,7 @@ __device__ __forceinline__ void sincos_f32_small(float a, float& s, float& c) {
     c = ((q + 1) & 2) ? -c1 : c1;
 }
 // The end points of line_params() with a SINGLE-precision sincos instead of the f64 one -- for the binning pass, where the
-// f64 sincos is most of the vector work.  The reference's cosf is the correctly rounded one (sincos_like_libm), so this
+// f64 sincos is most of the vector work.  The reference's cosf is glibc's (sincos_like_libm, within 0.56 ulp), so this
 // cd may differ from it by a couple of ulp, which moves an end point by |h| * 6e-7 cells at most: the ROUNDED end points
 // are the reference's unless a coordinate sits that close to a half-integer.  `ambiguous` says so (margin: 6e-7 relative
 // on the product -- 5 ulp -- plus 1e-7 cells), and for directions beyond +-64 rad; the caller then takes line_params().

@@ -61,7 +61,9 @@ def to_cloud(c, allow_device=True):
     return pc.to_device() if c["device"] and allow_device else pc
 
 
-@pytest.mark.parametrize("seed", range(40))
+# 48227: found by the round-5 soak -- one Line end point within 1e-7 of a rounding boundary, where glibc's sinf and the correctly
+# rounded sine differ in the last bit (csrc/libm_sincosf.hpp)
+@pytest.mark.parametrize("seed", list(range(40)) + [48227])
 def test_mixed_pipeline_matches_oracle(seed):
     check_mixed_pipeline(seed, pcr.ExecutionMode.GPU, "hip")
 
