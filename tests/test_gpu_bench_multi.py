@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, launcher=True, ranks=2):
+def _run(extra, launcher=True, ranks=2, extra_env=None):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -24,7 +24,7 @@ def _run(extra, launcher=True, ranks=2):
                "--master-port", str(port)] + tail
     else:
         cmd = [sys.executable] + tail          # the driver's form: bench.py starts its own ranks as a child process
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -93,3 +93,27 @@ def test_the_eight_rank_geometry_with_the_four_ranks_a_one_gpu_box_admits():
     assert g1["exchange"]["collectives_per_step"]["p2p_messages"] == 4          # rank 0: one neighbour, two planes, send + receive
     assert g1["exchange"]["halo_bytes_sent_per_step"] == 2 * 4 * 16384 * 4
     _check_selfcheck(r, ranks=4)
+
+
+def test_bench_times_the_native_exchange_and_compares_the_two_transports_on_the_test_double(tmp_path):
+    """`bench.py --comm native` with three ranks on one GPU: the library's own exchange is the TIMED transport, the selfcheck
+    runs through it, and `native_exchange` compares it with the torch transport bit for bit -- the part of the driver's N > 1
+    run that needs more than one rank, on the test double for RCCL (tests/native/fake_rccl.cpp; real RCCL admits one rank per
+    device).  2 048-row blocks on a 6 144-row grid cut the 4 096-row tiles: every step exchanges."""
+    import shutil
+    gxx = shutil.which("g++")
+    if not gxx or not os.path.isdir("/opt/rocm/include/rccl"):
+        pytest.skip("g++ or the RCCL headers are not available")
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"), "-o", fake, "-L/opt/rocm/lib", "-lamdhip64"], check=True)
+    r = _run(["--grid", "6144", "--points", "2000000", "--comm", "native"], ranks=3,
+             extra_env=dict(PCR_HIP_RCCL=fake, PCR_FAKE_RCCL_DIR=str(tmp_path)))
+    assert r["n_gpus"] == 3 and r["config"]["rows_per_gpu"] == 2048 and r["config"]["tiles_local"] is False
+    sc = r["selfcheck"]
+    assert sc["ok"] is True and sc["comm"] == "native", sc
+    assert sc["refinalize_owned_rows_unchanged"] is True and all(v == 0 for v in sc["refinalize_halo_rows_sum"])
+    ne = r["native_exchange"]
+    assert ne["ok"] is True and ne["ranks_bit_identical"] == 3, ne
+    g1 = r["per_glyph"]["gauss1"]
+    assert g1["exchange"]["comm"] == "native" and g1["exchange"]["halo_rows"] == 4

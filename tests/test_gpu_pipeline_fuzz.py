@@ -63,7 +63,8 @@ def to_cloud(c, allow_device=True):
 
 # 48227: found by the round-5 soak -- one Line end point within 1e-7 of a rounding boundary, where glibc's sinf and the correctly
 # rounded sine differ in the last bit (csrc/libm_sincosf.hpp)
-@pytest.mark.parametrize("seed", list(range(40)) + [48227])
+# 83506: a Gaussian cell of total weight 0.034 with a contribution on the 1e-6 cut-off (the allowance below)
+@pytest.mark.parametrize("seed", list(range(40)) + [48227, 83506])
 def test_mixed_pipeline_matches_oracle(seed):
     check_mixed_pipeline(seed, pcr.ExecutionMode.GPU, "hip")
 
@@ -131,4 +132,19 @@ def check_mixed_pipeline(seed, exec_mode, engine):
             mag = np.maximum(mag, np.nan_to_num(O.run(og, ort, cat["x"][keep], cat["y"][keep], np.abs(v), glyph=s["ogl"], wide=True, **chans)))
         err = np.abs(got[both].astype(np.float64) - exact[both])
         rtol = 1e-5 if s["kind"] == "point" else 1e-4
-        assert (err <= rtol * np.maximum(1e-2, mag[both])).all(), f"{what}: max err/mag {np.max(err / np.maximum(1e-2, mag[both])):.3g}"
+        tol = rtol * np.maximum(1e-2, mag[both])
+        if s["kind"] == "gauss":
+            # The splat paths form a weight as a product of per-axis factors (within 2 ulp of the reference's single expf), so a
+            # contribution sitting on the reference's `w < 1e-6f` cut-off (glyph_kernels.cu:166) may be kept where the reference
+            # drops it or the other way round; where a cell's total weight is itself tiny that one contribution is visible: TWO
+            # such contributions per cell are allowed, exactly as in tests/test_gpu_fuzz.py (soak seed 83506: cell weight 0.034,
+            # WeightedAverage off by 1.14e-4 of the cell's magnitude on the cell tiles, exact on the direct path).
+            vmax = float(np.max(np.abs(v), initial=0.0))
+            if s["rname"] == "Count":
+                tol = tol + 2e-6
+            elif s["rname"] == "Sum":
+                tol = tol + 2e-6 * vmax
+            else:
+                wsum = O.run(og, O.COUNT, cat["x"][keep], cat["y"][keep], v, glyph=s["ogl"], wide=True).astype(np.float64)
+                tol = tol + 2e-6 * (vmax + np.abs(exact[both])) / np.maximum(np.nan_to_num(wsum[both]), 1e-6)
+        assert (err <= tol).all(), f"{what}: max err/tol {np.max(err / tol):.3g}"

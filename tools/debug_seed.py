@@ -62,6 +62,21 @@ def report(tag, got, want):
 
 all_ids = list(range(len(clouds)))
 for i, s in enumerate(specs):
+    if s["kind"] == "gauss":
+        print("spec", i, {k: v for k, v in s.items() if k != "ogl"})
+        got = run(list(range(len(specs))), all_ids)[i]
+        want = oracle(i, all_ids)
+        cat = {k: np.concatenate([clouds[c][k] for c in all_ids]) for k in ("x", "y", "a", "b")}
+        wsum = O.run(og, O.COUNT, cat["x"], cat["y"], cat[s["ch"]], glyph=s["ogl"], wide=True).astype(np.float64)
+        mag = np.maximum(np.abs(want), np.nan_to_num(O.run(og, P.RT[s["rname"]][1], cat["x"], cat["y"], np.abs(cat[s["ch"]]), glyph=s["ogl"], wide=True)))
+        both = ~np.isnan(got) & ~np.isnan(want)
+        rel = np.zeros_like(want); rel[both] = np.abs(got[both] - want[both]) / np.maximum(1e-2, mag[both])
+        idx = np.unravel_index(np.argmax(rel), rel.shape)
+        print(f"  worst cell {idx}: got {got[idx]!r} want {want[idx]!r} rel {rel[idx]:.3g} total weight there {wsum[idx]:.6g} mag {mag[idx]:.4g}; cells over 1e-4: {(rel > 1e-4).sum()}")
+        for pth in (1, 2):
+            g2 = run([i], all_ids, path=pth)[0]
+            print(f"  path {pth}: got {g2[idx]!r} rel {abs(g2[idx] - want[idx]) / max(1e-2, mag[idx]):.3g}")
+        continue
     if s["kind"] != "line":
         continue
     print("spec", i, {k: v for k, v in s.items() if k != "ogl"})
