@@ -716,18 +716,40 @@ def main():
         res = {}
         sps = {}
         err = None
-        try:
-            for kind in ("torch", "native"):
-                sp = ShardedPipeline(make_cfg("C5_gauss1"), rank, world, device_id=local_rank, comm=kind)
-                sp.ingest(cloud)
-                sps[kind] = sp
+        # Set-up in stages, each closed by an all-reduce of an error flag: a rank whose local part fails (no cloud, out of
+        # memory) must not leave the others waiting inside the NEXT stage's collective (creating a native pipeline broadcasts
+        # the communicator's id).
+        def agreed(stage, fn):
+            nonlocal err
+            if not err:
+                try:
+                    fn()
+                except Exception as exc:
+                    err = f"{stage}: {exc!r}"
+            flag = torch.tensor([1 if err else 0], dtype=torch.int64, device="cpu" if cpu else "cuda")
+            dist.all_reduce(flag)
+            return int(flag.item())
+
+        def make(kind):
+            sps[kind] = ShardedPipeline(make_cfg("C5_gauss1"), rank, world, device_id=local_rank, comm=kind)
+
+        def ingest_both():
+            # ONE ingest, then the same bits in both pipelines: the Gaussian tiles merge into the planes with float atomics, so
+            # two ingests of one cloud differ in the last bit -- what is compared here is the exchange, not the scatter
+            a, b = sps["torch"], sps["native"]
+            a.ingest(cloud)
+            a.pipe.synchronize()
             torch.cuda.synchronize()
-        except Exception as exc:
-            err = repr(exc)
-        flag = torch.tensor([1 if err else 0], dtype=torch.int64, device="cpu" if cpu else "cuda")
-        dist.all_reduce(flag)
-        if int(flag.item()):
-            return {"ok": False, "error": f"set-up failed on {int(flag.item())} rank(s)" + (f"; this rank: {err}" if err else "")}
+            for (ta, _), (tb, _) in zip(a._plane_tensors(), b._plane_tensors()):
+                tb.copy_(ta)
+            b._touched.copy_(a._touched)
+            torch.cuda.synchronize()
+
+        for stage, fn in (("prerequisites", lambda: cloud.count()), ("torch pipeline", lambda: make("torch")),
+                          ("native pipeline", lambda: make("native")), ("ingest", ingest_both)):
+            bad = agreed(stage, fn)
+            if bad:
+                return {"ok": False, "error": f"set-up failed on {bad} rank(s)" + (f"; this rank: {err}" if err else "")}
         for kind in ("torch", "native"):
             sps[kind].exchange(timed=True)
             sps[kind].pipe.synchronize()
@@ -914,7 +936,8 @@ def main():
         one = None
         if rank == 0:
             try:
-                del cloud
+                # (this rank's own cloud stays: the native-exchange check below ingests it again -- round 4 deleted it here to
+                # save 2.5 GB of 288, and rank 0 then failed the check's set-up while the others waited in its broadcast)
                 total_pts = n * world
                 whole = device_cloud_uniform(total_pts, 2.0, G - 2.0, 2.0, H - 2.0, seed=42)
                 cfg1 = make_cfg(workload)
@@ -950,6 +973,11 @@ def main():
 
         def bail():
             # a collective of the check never returned: the measurements above are complete -- print them and leave
+            try:                                     # where every thread of this rank is stuck, for whoever reads the log
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            except Exception:
+                pass
             with lock:
                 if state["printed"]:
                     return

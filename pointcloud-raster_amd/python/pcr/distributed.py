@@ -277,10 +277,15 @@ def _native_comm(rank, world, device, group=None):
         raise RuntimeError("ShardedPipeline(comm='native'): RCCL is not available to libpcr_hip.so")
     box = [None]
     if rank == 0:
-        buf = (C.c_uint8 * 128)()
-        A.check(L.pcr_hip_comm_unique_id(buf))
-        box[0] = bytes(buf)
+        try:
+            buf = (C.c_uint8 * 128)()
+            A.check(L.pcr_hip_comm_unique_id(buf))
+            box[0] = bytes(buf)
+        except Exception as exc:                 # the others are waiting in the broadcast: they get the reason instead of the id
+            box[0] = ("error", str(exc))
     dist.broadcast_object_list(box, src=0, group=group)
+    if isinstance(box[0], tuple):
+        raise RuntimeError("ShardedPipeline(comm='native'): rank 0 could not make the communicator's id: " + box[0][1])
     ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
     handle = C.c_void_p()
     A.check(L.pcr_hip_comm_create(C.byref(handle), ident, rank, world, int(device)))
