@@ -15,7 +15,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 def kernels(src):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        extra = os.environ.get("PCR_EXTRA_FLAGS", "").split()          # e.g. PCR_EXTRA_FLAGS="-DPCR_ROUTE_PER=16"
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + [src, "-o", out], check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     meta = text[text.index("amdhsa.kernels:"):]
     rows = []
