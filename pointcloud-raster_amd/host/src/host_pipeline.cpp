@@ -59,23 +59,10 @@ Status Pipeline::Host::ingest(const PointCloud& cloud_in) {
         if (!copy) return Status::error(StatusCode::OutOfMemory, "pipeline: cannot copy the device cloud to the host");
         cloud = copy.get();
     }
-    // filter predicates: same checks and messages as filter_points (src/engine/filter.cpp:101-123)
-    for (const auto& pr : cfg.filter.predicates) {
-        if (!cloud->channel_data(pr.channel_name))
-            return Status::error(StatusCode::InvalidArgument, "filter_points: channel not found: " + pr.channel_name);
-        const ChannelDesc* d = cloud->channel(pr.channel_name);
-        if (!d || d->dtype != DataType::Float32)
-            return Status::error(StatusCode::InvalidArgument, "filter_points: only Float32 channels supported for filtering");
-    }
-    for (const auto& r : cfg.reductions) {                           // pipeline.cpp:365-378, 500-508
-        if (!cloud->channel_data(r.value_channel))
-            return Status::error(StatusCode::InvalidArgument, "pipeline: value channel not found: " + r.value_channel);
-        const ChannelDesc* d = cloud->channel(r.value_channel);
-        if (!d || d->dtype != DataType::Float32)
-            return Status::error(StatusCode::InvalidArgument, "pipeline: value channel must be Float32");
-        if (r.glyph.type != GlyphType::Point && !glyph_reduction_ok(r.type))
-            return Status::error(StatusCode::NotImplemented,
-                "pipeline: glyph splatting only supports WeightedAverage, Average, Sum, or Count reduction types");
+    // the reference's checks and messages (pipeline_common.cpp; no device limits on the host)
+    {
+        Status ok = detail::validate_cloud(cfg, *cloud, 0, 0);
+        if (!ok.ok()) return ok;
     }
     auto f32 = [&](const std::string& name) -> const float* {
         if (name.empty()) return nullptr;

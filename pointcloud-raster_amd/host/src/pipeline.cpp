@@ -418,32 +418,10 @@ struct Pipeline::Impl {
         const size_t n = cloud.count();
         if (n == 0) return Status::success();
         DeviceScope dev(cfg.cuda_device_id);
-        // filter predicates: same checks and messages as filter_points (src/engine/filter.cpp:101-123)
-        for (const auto& pr : cfg.filter.predicates) {
-            if (!cloud.channel_data(pr.channel_name))
-                return Status::error(StatusCode::InvalidArgument, "filter_points: channel not found: " + pr.channel_name);
-            const ChannelDesc* d = cloud.channel(pr.channel_name);
-            if (!d || d->dtype != DataType::Float32)
-                return Status::error(StatusCode::InvalidArgument,
-                                     "filter_points: only Float32 channels supported for filtering");
-            if (pr.value_set.size() > PCR_HIP_MAX_FILTER_SET)
-                return Status::error(StatusCode::InvalidArgument,
-                                     "filter_points: value_set larger than 16 entries is not supported on the device");
-        }
-        if (cfg.filter.predicates.size() > PCR_HIP_MAX_FILTER_PREDICATES)
-            return Status::error(StatusCode::InvalidArgument, "filter_points: more than 16 predicates");
-
-        // validate every reduction before touching state
-        for (const auto& r : cfg.reductions) {
-            if (!cloud.channel_data(r.value_channel))
-                return Status::error(StatusCode::InvalidArgument,
-                                     "pipeline: value channel not found: " + r.value_channel);
-            const ChannelDesc* d = cloud.channel(r.value_channel);
-            if (!d || d->dtype != DataType::Float32)
-                return Status::error(StatusCode::InvalidArgument, "pipeline: value channel must be Float32");
-            if (r.glyph.type != GlyphType::Point && !glyph_reduction_ok(r.type))
-                return Status::error(StatusCode::NotImplemented,
-                    "pipeline: glyph splatting only supports WeightedAverage, Average, Sum, or Count reduction types");
+        // validate every predicate and reduction before touching state (pipeline_common.cpp: the reference's checks and messages)
+        {
+            Status ok = detail::validate_cloud(cfg, cloud, PCR_HIP_MAX_FILTER_SET, PCR_HIP_MAX_FILTER_PREDICATES);
+            if (!ok.ok()) return ok;
         }
 
         const MemoryLocation loc = cloud.location();
@@ -978,14 +956,54 @@ struct Pipeline::Banded {
         return sub;
     }
 
+    // Survivors of the filter, as the bands' own ingests will count them (the same kernel on the same channels): what
+    // points_processed grows by (src/engine/pipeline.cpp:749), whether or not any band is visited.
+    Status count_kept(const PointCloud& dev, size_t* kept) {
+        const size_t n = dev.count();
+        *kept = n;
+        if (cfg.filter.empty()) return Status::success();
+        Impl::DeviceScope scope(cfg.cuda_device_id);
+        std::vector<pcr_hip_predicate> preds(cfg.filter.predicates.size());
+        for (size_t k = 0; k < preds.size(); ++k) {
+            const FilterPredicate& pr = cfg.filter.predicates[k];
+            preds[k].d_channel = static_cast<const float*>(dev.channel_data(pr.channel_name));
+            preds[k].op = static_cast<int32_t>(pr.op);
+            preds[k].value = pr.value;
+            preds[k].set_size = static_cast<int32_t>(pr.value_set.size());
+            for (size_t j = 0; j < pr.value_set.size(); ++j) preds[k].set[j] = pr.value_set[j];
+        }
+        detail::Buffer mb;                                   // [u64 survivor count][mask bytes]
+        Status s = mb.allocate(n + 16, MemoryLocation::Device);
+        if (!s.ok()) return s;
+        unsigned long long h_count = 0;
+        if (!(s = detail::hip_status(pcr_hip_filter_mask(preds.data(), (int)preds.size(), n, static_cast<uint8_t*>(mb.data()) + 8,
+                                                         static_cast<unsigned long long*>(mb.data()), nullptr))).ok()) return s;
+        if (!(s = detail::hip_status(pcr_hip_memcpy_d2h(&h_count, mb.data(), sizeof h_count, nullptr))).ok()) return s;
+        if (!(s = detail::hip_status(pcr_hip_stream_synchronize(nullptr))).ok()) return s;
+        *kept = (size_t)h_count;
+        return Status::success();
+    }
+
     Status ingest(const PointCloud& cloud) {
         if (cloud.count() == 0) return Status::success();
+        // the checks every band's ingest would make, made once and whether or not the cloud reaches a band
+        Status ok = detail::validate_cloud(cfg, cloud, PCR_HIP_MAX_FILTER_SET, PCR_HIP_MAX_FILTER_PREDICATES);
+        if (!ok.ok()) return ok;
         // one device copy of a host cloud for all bands (each band's kernels read every point and keep its own)
         std::unique_ptr<PointCloud> staged;
         const PointCloud* src = &cloud;
         if (cloud.location() != MemoryLocation::Device) {
             staged = cloud.to(MemoryLocation::Device);
             if (staged) src = staged.get();
+        }
+        // points_processed counts the filter's survivors (round 5's fuzz: it counted the cloud); none: nothing to do, and the
+        // ingest is not a collection either (src/engine/pipeline.cpp:349-353)
+        size_t kept = cloud.count();
+        bool kept_known = cfg.filter.empty();
+        if (!kept_known && src->location() == MemoryLocation::Device) {
+            if (!(ok = count_kept(*src, &kept)).ok()) return ok;
+            kept_known = true;
+            if (kept == 0) return Status::success();
         }
         // Which bands does this cloud reach at all?  One routing pass over x, y (pcr_hip_route_count with the bands as the parts:
         // 16 B per point, ~0.2 ms per 100 M points) against ~50 ms per band VISITED (a sub-pipeline, the band's state over
@@ -1020,6 +1038,7 @@ struct Pipeline::Banded {
             std::unique_ptr<Pipeline> sub = visit(b, &s, &from_disk);
             if (!sub) return s;
             if (!(s = sub->ingest(*src)).ok()) return s;
+            if (!kept_known) { kept = (size_t)sub->stats().points_processed; kept_known = true; }   // (a fresh sub-pipeline: this ingest's survivors)
             const ScatterInfo here = sub->last_scatter();
             valid_total += here.points_valid;
             last = here;
@@ -1036,7 +1055,7 @@ struct Pipeline::Banded {
         last.points_in = cloud.count();                                     // (of the whole ingest: every band saw every point)
         last.points_valid = valid_total;
         ++collections;
-        points += cloud.count();
+        points += kept;
         if (callback) {
             ProgressInfo info = stats();
             if (!callback(info)) return Status::error(StatusCode::InvalidArgument, "pipeline: cancelled by user");

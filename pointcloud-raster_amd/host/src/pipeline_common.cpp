@@ -1,6 +1,7 @@
-// pipeline_common.cpp -- `.pcrt` tile files of a window of state planes (see pipeline_common.h).
+// pipeline_common.cpp -- what the engines behind pcr::Pipeline share: the cloud checks, `.pcrt` tile files of a window of state planes (see pipeline_common.h).
 #include "pipeline_common.h"
 
+#include "pcr/core/point_cloud.h"
 #include "pcr/io/tile_state_io.h"
 
 #include <algorithm>
@@ -8,6 +9,32 @@
 
 namespace pcr {
 namespace detail {
+
+Status validate_cloud(const PipelineConfig& cfg, const PointCloud& cloud, size_t max_set, size_t max_predicates) {
+    for (const auto& pr : cfg.filter.predicates) {
+        if (!cloud.channel_data(pr.channel_name))
+            return Status::error(StatusCode::InvalidArgument, "filter_points: channel not found: " + pr.channel_name);
+        const ChannelDesc* d = cloud.channel(pr.channel_name);
+        if (!d || d->dtype != DataType::Float32)
+            return Status::error(StatusCode::InvalidArgument, "filter_points: only Float32 channels supported for filtering");
+        if (max_set && pr.value_set.size() > max_set)
+            return Status::error(StatusCode::InvalidArgument,
+                                 "filter_points: value_set larger than " + std::to_string(max_set) + " entries is not supported on the device");
+    }
+    if (max_predicates && cfg.filter.predicates.size() > max_predicates)
+        return Status::error(StatusCode::InvalidArgument, "filter_points: more than " + std::to_string(max_predicates) + " predicates");
+    for (const auto& r : cfg.reductions) {
+        if (!cloud.channel_data(r.value_channel))
+            return Status::error(StatusCode::InvalidArgument, "pipeline: value channel not found: " + r.value_channel);
+        const ChannelDesc* d = cloud.channel(r.value_channel);
+        if (!d || d->dtype != DataType::Float32)
+            return Status::error(StatusCode::InvalidArgument, "pipeline: value channel must be Float32");
+        if (r.glyph.type != GlyphType::Point && !glyph_reduction_ok(r.type))
+            return Status::error(StatusCode::NotImplemented,
+                "pipeline: glyph splatting only supports WeightedAverage, Average, Sum, or Count reduction types");
+    }
+    return Status::success();
+}
 
 std::string reduction_state_dir(const std::string& dir, size_t r, size_t n_outputs) {
     return n_outputs == 1 ? dir : dir + "/reduction_" + std::to_string(r);

@@ -106,6 +106,11 @@ struct StateWindow {
 
 /// "<dir>" for a single reduction (the reference's layout), "<dir>/reduction_<r>" otherwise.
 std::string reduction_state_dir(const std::string& dir, size_t r, size_t n_outputs);
+
+// What every engine checks of a cloud before it touches any state, with the reference's messages: the filter's channels
+// (filter_points, src/engine/filter.cpp:101-123), every reduction's value channel and glyph / reduction pairing
+// (src/engine/pipeline.cpp:365-378, 500-508).  max_set / max_predicates: the device filter's limits (0 = none, host engine).
+Status validate_cloud(const PipelineConfig& cfg, const PointCloud& cloud, size_t max_set, size_t max_predicates);
 /// One `.pcrt` file per touched reference tile inside the window and per output (src/io/tile_state_io.cpp:45-95;
 /// file name src/io/tile_state_io.cpp:197-211).  touched: tiles_x * tiles_y flags of the whole grid.
 Status write_state_tiles(const GridConfig& g, const std::vector<StateOutput>& outputs, const StateWindow& w,
