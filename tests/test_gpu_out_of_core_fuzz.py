@@ -6,7 +6,7 @@ optional filter, and -- half of the time -- a checkpoint in the middle: save_sta
 resumes from it.  Every band must equal the IN-CORE pipeline's on the same ingests: bit for bit where no float atomic is involved
 and both pipelines are bound to take the same path (Max, Min, Count of Points and Lines), to fp32 re-association otherwise (a
 band's sub-pipeline may pick the direct path where the whole grid is binned).  Seeds 0..11 in the suite; PCR_OOC_FUZZ_SEEDS=a:b
-soaks a range.  A failure names its seed."""
+soaks a range (or a,b,c: those seeds).  A failure names its seed."""
 import os
 
 import numpy as np
@@ -24,9 +24,11 @@ RT = {"Sum": pcr.ReductionType.Sum, "Max": pcr.ReductionType.Max, "Min": pcr.Red
 
 def seeds():
     env = os.environ.get("PCR_OOC_FUZZ_SEEDS")
-    if env:
+    if env and ":" in env:
         a, b = env.split(":")
         return list(range(int(a), int(b)))
+    if env:
+        return [int(v) for v in env.split(",")]
     return list(range(12))
 
 
@@ -135,36 +137,51 @@ def test_out_of_core_equals_in_core(seed, tmp_path):
         assert ooc.stats().points_processed == incore.stats().points_processed, f"seed {seed}: points_processed"
     else:
         assert processed + ooc.stats().points_processed == incore.stats().points_processed, f"seed {seed}: points_processed over the checkpoint"
+    got = [np.array(ooc.result().band_array(i)) for i in range(len(specs))]
+    assert_bands_match(f"seed {seed} (banded={banded}, knobs={knobs})", og, specs, filt, clouds, got, want)
+
+
+def assert_bands_match(desc, og, specs, filt, clouds, got_bands, want_bands):
+    """Bands of two pipelines of THIS library over the same ingests (tests/test_gpu_sharded_fuzz.py uses it too): bit for bit
+    where no float atomic is involved (Max, Min, Count of Points and Lines), to fp32 re-association otherwise."""
     for i, s in enumerate(specs):
-        what = f"seed {seed} (banded={banded}, knobs={knobs}) band {i}: {s['kind']}/{s['rname']}"
-        got = np.array(ooc.result().band_array(i))
-        assert got.shape == want[i].shape == (og.height, og.width), what
-        gn, wn = np.isnan(got), np.isnan(want[i])
+        what = f"{desc} band {i}: {s['kind']}/{s['rname']}"
+        got, want = got_bands[i], want_bands[i]
+        assert got.shape == want.shape == (og.height, og.width), what
+        gn, wn = np.isnan(got), np.isnan(want)
         assert np.array_equal(gn, wn), f"{what}: NaN mask differs in {(gn != wn).sum()} cells"
         m = ~gn
         if s["rname"] in ("Max", "Min") or (s["rname"] == "Count" and s["kind"] != "gauss"):
-            assert np.array_equal(got[m], want[i][m]), what
+            assert np.array_equal(got[m], want[m]), what
             continue
-        # sums: the same contributions in another order (per band: another path, other tiles, other atomics)
-        scale = np.maximum(np.abs(want[i][m]), 1e-2)
-        if s["rname"] in ("Average", "WeightedAverage"):
-            scale = np.maximum(scale, 8.0)                       # |a| <~ 13, |b| <= 1: a mean's error scales with the values, not the mean
-        err = np.abs(got[m].astype(np.float64) - want[i][m])
+        # sums: the same contributions in another order (per band: another path, other tiles, other atomics) -- the error of a
+        # cell scales with the MAGNITUDES that met there (channel b is +-1: its sums cancel), which the oracle supplies
+        cat = {k: np.concatenate([c[k] for c in clouds]) for k in ("x", "y", "a", "b", "cls", "dir")}
+        keep = cat["cls"] < filt[0] if filt else np.ones(len(cat["x"]), dtype=bool)
+        x, y, v = cat["x"][keep], cat["y"][keep], cat[s["ch"]][keep]
+        vmax = float(np.max(np.abs(v), initial=0.0))
+        ogl, chans = None, {}
+        if s["kind"] == "gauss":
+            ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=s["sigma"], sigma_y=s["sigma"], max_radius=s["maxr"])
+        elif s["kind"] == "line":
+            ogl, chans = O.make_glyph(O.GLYPH_LINE, half_length=s["hl"], max_radius=16.0), dict(direction=cat["dir"][keep])
+        if s["rname"] == "Sum":
+            scale = np.maximum(np.nan_to_num(O.run(og, O.SUM, x, y, np.abs(v), glyph=ogl, wide=True, **chans).astype(np.float64))[m], 1e-2)
+        elif s["rname"] == "Count":
+            scale = np.maximum(np.abs(want[m]), 1e-2)
+        else:
+            scale = np.maximum(np.abs(want[m]), max(vmax, 1e-2))      # a mean's error scales with the values, not with the mean
+        err = np.abs(got[m].astype(np.float64) - want[m])
         tol = 2e-5 * scale
         if s["kind"] == "gauss":
             # a band's sub-pipeline may take another Gaussian path than the whole grid does, and the paths may disagree about
             # a contribution that sits on the reference's `w < 1e-6f` cut-off (glyph_kernels.cu:166; tests/test_gpu_pipeline_fuzz.py):
             # two such contributions per cell are allowed, visible only where the cell's total weight is itself tiny
-            cat = {k: np.concatenate([c[k] for c in clouds]) for k in ("x", "y", "a", "b", "cls")}
-            keep = cat["cls"] < filt[0] if filt else np.ones(len(cat["x"]), dtype=bool)
-            v = cat[s["ch"]][keep]
-            vmax = float(np.max(np.abs(v), initial=0.0))
             if s["rname"] == "Count":
                 tol = tol + 2e-6
             elif s["rname"] == "Sum":
                 tol = tol + 2e-6 * vmax
             else:
-                ogl = O.make_glyph(O.GLYPH_GAUSSIAN, sigma_x=s["sigma"], sigma_y=s["sigma"], max_radius=s["maxr"])
-                wsum = O.run(og, O.COUNT, cat["x"][keep], cat["y"][keep], v, glyph=ogl, wide=True).astype(np.float64)
-                tol = tol + 2e-6 * (vmax + np.abs(want[i][m])) / np.maximum(np.nan_to_num(wsum[m]), 1e-6)
+                wsum = O.run(og, O.COUNT, x, y, v, glyph=ogl, wide=True).astype(np.float64)
+                tol = tol + 2e-6 * (vmax + np.abs(want[m])) / np.maximum(np.nan_to_num(wsum[m]), 1e-6)
         assert (err <= tol).all(), f"{what}: max err / tol {np.max(err / tol):.3g}"
