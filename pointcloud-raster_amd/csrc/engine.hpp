@@ -90,8 +90,12 @@ struct BinBuffers {                     // device pointers into the engine's scr
     const unsigned* n_items;            // [0] = items, [1] = 1 when some bin was split into several items
     int max_items;
 };
-constexpr int kMaxBins = 8064;         // scatter pass LDS: 8192-point chunk (64 KB) + 8 B per bin; beyond this the runs a
-                                        // block writes per bin are single records anyway (two-level sort / row bands)
+constexpr int kMaxBins = 12160;        // scatter pass LDS: the 8192-record staging window (64 KB) + 8 B per bin = 159 KB of the CU's 160.
+                                        // Round 5 (8064 until then, "beyond this a block's runs are single records anyway"): measured on
+                                        // the window of a C5 shard at N = 2 (16384 x 8192, 11 008 tiles, 500 M points) one level with
+                                        // runs of ~2 records costs 5.79 ms a step, the two-level sort 7.18, two row bands 9.09
+                                        // (tools/n2_shard_ab.sh) -- the second level's two passes over the records cost more than the
+                                        // partial lines do.  Beyond this: two-level sort / row bands.
 constexpr int kLcellBits = 15;          // up to 32768 cells per LDS tile
 constexpr int kMaxTiles = 1 << (32 - kLcellBits);   // routing key = tile << 15 | local cell
 constexpr int kMaxSubBins = 2048;       // tiles per first-level group (second-level scatter: 128 KB staging + 12 B per tile)

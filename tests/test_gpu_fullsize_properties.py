@@ -97,14 +97,16 @@ def test_c2_paths_and_permutation_agree(data):
     np.testing.assert_allclose(s, s2, rtol=1e-5, atol=1e-5)           # fp32 re-association only
 
 
-def test_large_grid_paths_agree_at_full_size():
-    """16384 x 16384 (21 888 Point tiles > 8064: the two-level sort) with 30 M points, no oracle: Count / Max / Min
-    must be bit-identical to the direct-atomics path, Sum within float32 accumulation noise, counts conserved.
+@pytest.mark.parametrize("height", [16384, 8192], ids=["37504-tiles:two-level", "11008-tiles:one-level"])
+def test_large_grid_paths_agree_at_full_size(height):
+    """16384 x 16384 with four planes (37 504 Point tiles: the two-level sort) and 16384 x 8192 with Sum + Count (11 008 tiles, the
+    window of a C5 shard at N = 2: one sort level since round 5, kMaxBins = 12 160) with 30 M points, no oracle: Count / Max / Min must be bit-identical
+    to the direct-atomics path, Sum within float32 accumulation noise, counts conserved.
     Runs in a fresh interpreter because it generates its points with torch, which must be imported before pcr."""
     import os
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_large_grid_worker.py")
-    out = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, worker, str(height)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "large grid paths agree" in out.stdout
