@@ -166,3 +166,37 @@ def test_pipeline_loads_reference_written_tile(tmp_path):
     q = pcr.Pipeline.create(_cfg([_spec(pcr.ReductionType.Average)], state_dir=str(d), resume=True))
     q.finalize()
     assert np.isnan(np.array(q.result().band_array(0))[0:5, 0:5]).all()
+
+
+@pytest.mark.parametrize("engine", ["host", pytest.param("hip", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("damage", ["truncated", "bad_magic", "wrong_shape", "empty"])
+def test_damaged_tile_files_are_treated_as_absent_on_resume(tmp_path, damage, engine):
+    """The reference's tile manager re-initialises a tile whose file does not read back (corrupt, truncated, of another shape:
+    src/engine/tile_manager.cpp:272-320) instead of failing the run; so does resume here -- the damaged tile starts from
+    identity, its neighbours come back.  On both engines (one load code: host/src/pipeline_common.cpp)."""
+    d = str(tmp_path)
+    good = np.arange(50, dtype=np.float32).reshape(2, 5, 5) + 1.0            # {sum, count} of an Average tile, all cells counted
+    pcr.write_tile_state(pcr.tile_state_filename(d, 0, 0), 0, 0, good, pcr.ReductionType.Average)
+    bad = pcr.tile_state_filename(d, 1, 1)
+    pcr.write_tile_state(bad, 1, 1, good, pcr.ReductionType.Average)
+    data = open(bad, "rb").read()
+    if damage == "truncated":
+        open(bad, "wb").write(data[:60])
+    elif damage == "bad_magic":
+        open(bad, "wb").write(b"XXXX" + data[4:])
+    elif damage == "wrong_shape":
+        pcr.write_tile_state(bad, 1, 1, np.ones((2, 4, 5), np.float32), pcr.ReductionType.Average)     # a 5 x 4 tile where the grid has 5 x 5
+    else:
+        open(bad, "wb").close()
+    cfg = _cfg([_spec(pcr.ReductionType.Average)], state_dir=d, resume=True)
+    cfg.exec_mode = pcr.ExecutionMode.CPU if engine == "host" else pcr.ExecutionMode.GPU
+    p = pcr.Pipeline.create(cfg)
+    assert p is not None, pcr.pipeline_create_error()
+    assert p.engine() == engine
+    p.ingest(_cloud([7.5], [2.5], [3.0]))                                     # one point into the damaged tile: cell (row 7, col 7)
+    p.finalize()
+    band = np.array(p.result().band_array(0))
+    assert np.allclose(band[0:5, 0:5], good[0] / good[1])                     # the intact tile came back
+    want = np.full((5, 5), np.nan, np.float32)
+    want[2, 2] = 3.0
+    assert np.array_equal(band[5:10, 5:10], want, equal_nan=True)             # the damaged one started from identity
